@@ -1,0 +1,137 @@
+"""ctypes binding of the C ABI in include/i2s.h (libi2s_hip.so).
+
+The product path has NO CPU fallback: `load()` raises if the HIP library is missing or cannot be
+loaded, and `i2s_create` fails when no GPU is visible.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libi2s_hip.so")
+
+BOARD_SIZE = 19
+NSLOTS = 10
+MAX_CIRCLES = 4096
+MAX_LINES = 1024
+MAX_CENTRES = 256
+PLANE_NAMES = {"grey": 0, "edges": 1, "median3": 2, "gauss3": 3, "median5": 4, "gauss5": 5, "median7": 6,
+               "gauss7": 7, "removed": 8, "canny_map": 9}
+
+STATUS_TEXT = {
+    0: "board ready", 1: "no horizontal grid lines found", 2: "only one horizontal grid line",
+    3: "horizontal grid lines too close together", 4: "horizontal grid too wide (extra lines?)",
+    5: "no vertical grid lines found", 6: "only one vertical grid line",
+    7: "vertical grid lines too close together", 8: "vertical grid too wide (extra lines?)",
+    9: "too many vertical lines", 10: "too many horizontal lines", 100: "capacity exceeded",
+}
+
+
+class I2sParams(C.Structure):
+    _fields_ = [
+        ("canny_lo", C.c_int32), ("canny_hi", C.c_int32),
+        ("hc_min_dist", C.c_float),
+        ("hc_param1", C.c_int32), ("hc_param2", C.c_int32),
+        ("hc_min_radius", C.c_int32), ("hc_max_radius", C.c_int32),
+        ("line_threshold", C.c_int32), ("black_threshold", C.c_int32),
+        ("align_x", C.c_int32), ("align_y", C.c_int32),
+        ("min_grid_spacing", C.c_double), ("big_space_ratio", C.c_double), ("angle_tolerance_deg", C.c_double),
+        ("grey_shift", C.c_int32), ("gauss_kernel_mode", C.c_int32), ("houghlines_numangle_mode", C.c_int32),
+        ("inputs_on_device", C.c_int32),
+    ]
+
+
+class I2sBoard(C.Structure):
+    _fields_ = [
+        ("board", (C.c_uint8 * BOARD_SIZE) * BOARD_SIZE),
+        ("status", C.c_uint8), ("side_to_move", C.c_uint8), ("hsize", C.c_uint8), ("vsize", C.c_uint8),
+        ("found_grid", C.c_uint8), ("valid_grid", C.c_uint8), ("pad0", C.c_uint8),
+        ("n_black", C.c_uint16), ("n_white", C.c_uint16), ("n_circles", C.c_uint16), ("line_threshold", C.c_uint16),
+        ("pad", C.c_uint8 * 8),
+    ]
+
+
+class I2sResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("line_threshold", C.c_int32),
+        ("found_grid", C.c_int32), ("valid_grid", C.c_int32), ("board_ready", C.c_int32),
+        ("hsize", C.c_int32), ("vsize", C.c_int32),
+        ("n_circles", C.c_int32), ("n_per_slot", C.c_int32 * NSLOTS), ("n_circles_kept", C.c_int32),
+        ("n_hlines", C.c_int32), ("n_vlines", C.c_int32),
+        ("n_hcentres", C.c_int32), ("n_vcentres", C.c_int32),
+        ("n_hcomplete", C.c_int32), ("n_vcomplete", C.c_int32),
+        ("n_stones", C.c_int32), ("n_black", C.c_int32), ("n_white", C.c_int32), ("side_to_move", C.c_int32),
+        ("pad0", C.c_int32),
+        ("hspace", C.c_double), ("vspace", C.c_double),
+        ("hcentres", C.c_double * MAX_CENTRES), ("vcentres", C.c_double * MAX_CENTRES),
+        ("hcentres_complete", C.c_double * MAX_CENTRES), ("vcentres_complete", C.c_double * MAX_CENTRES),
+        ("brightness", C.c_double * (BOARD_SIZE * BOARD_SIZE)),
+        ("hlines", C.c_float * MAX_LINES), ("vlines", C.c_float * MAX_LINES),
+        ("circles", (C.c_float * 3) * MAX_CIRCLES),
+        ("circle_kept", C.c_uint8 * MAX_CIRCLES),
+        ("detected", (C.c_uint8 * BOARD_SIZE) * BOARD_SIZE),
+        ("board", (C.c_uint8 * BOARD_SIZE) * BOARD_SIZE),
+        ("pad1", C.c_uint8 * 2),
+    ]
+
+
+assert C.sizeof(I2sBoard) == 384
+assert C.sizeof(I2sResult) == 73384
+
+EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
+           "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_classify_batch", "i2s_grid_from_lines",
+           "i2s_fetch_plane", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc"]
+
+
+class I2sError(RuntimeError):
+    pass
+
+
+class I2sLibrary:
+    """A loaded C-ABI library with typed entry points."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise I2sError(
+                "HIP library %s not found: build it with `python -m img2sgf_amd.build` "
+                "(there is no CPU fallback)" % path)
+        self.path = path
+        L = self.dll = C.CDLL(path)
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise I2sError("%s does not export %s" % (path, name))
+        vp, ip, u8p, f32p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+        L.i2s_abi_version.restype = C.c_int
+        L.i2s_default_params.argtypes = [C.POINTER(I2sParams)]
+        L.i2s_default_params.restype = None
+        L.i2s_choose_threshold.argtypes = [C.c_int, C.c_int]
+        L.i2s_strerror.argtypes = [C.c_int]
+        L.i2s_strerror.restype = C.c_char_p
+        L.i2s_last_error.argtypes = [vp]
+        L.i2s_last_error.restype = C.c_char_p
+        L.i2s_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.i2s_destroy.argtypes = [vp]
+        L.i2s_destroy.restype = None
+        L.i2s_detect_batch.argtypes = [vp, C.c_int, C.POINTER(vp), ip, ip, ip, ip, C.POINTER(I2sParams),
+                                       C.POINTER(I2sBoard), C.POINTER(I2sResult)]
+        L.i2s_classify_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(I2sParams), C.POINTER(I2sBoard),
+                                         C.POINTER(I2sResult)]
+        L.i2s_grid_from_lines.argtypes = [vp, u8p, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int,
+                                          C.POINTER(I2sParams), C.POINTER(I2sBoard), C.POINTER(I2sResult)]
+        L.i2s_fetch_plane.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.i2s_last_timing.argtypes = [vp, f32p]
+        L.i2s_set_debug.argtypes = [vp, C.c_int]
+        L.i2s_fetch_circle_acc.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        L.i2s_fetch_line_acc.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_size_t, ip, ip]
+        if L.i2s_abi_version() != 1:
+            raise I2sError("ABI version mismatch in %s" % path)
+
+
+_DEFAULT = None
+
+
+def load():
+    """The product library (libi2s_hip.so next to this file).  Raises I2sError if it is missing."""
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = I2sLibrary(LIB_PATH)
+    return _DEFAULT

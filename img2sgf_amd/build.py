@@ -1,0 +1,35 @@
+"""Builds libi2s_hip.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libi2s_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    inc = os.path.join(os.path.dirname(HERE), "include", "i2s.h")
+    return any(os.path.getmtime(f) > t for f in sources() + [inc])
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles without a GPU; returns the path of the shared library."""
+    if force or needs_build():
+        cmd = ["hipcc"] + FLAGS + ["-o", LIB, os.path.join(CSRC, "i2s_api.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

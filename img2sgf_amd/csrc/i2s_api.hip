@@ -1,0 +1,494 @@
+// C ABI of libi2s_hip.so (include/i2s.h): context, device workspace and the kernel pipeline.
+// One context = one GPU = one HIP stream; a detect call streams the batch through the device in passes of
+// `max_batch` images with a single synchronisation per pass.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "i2s_types.h"
+#include "k_canny.h"
+#include "k_erase_lines.h"
+#include "k_filters.h"
+#include "k_grid.h"
+#include "k_hough_circles.h"
+
+using namespace i2s;
+
+namespace {
+constexpr int NPLANES = I2S_PLANE__COUNT;    // 8 variant planes, removed, 9 maps
+constexpr int HYST_MAX_PASSES = 4096;
+constexpr int RAD_GX = 32;
+}  // namespace
+
+struct i2s_ctx {
+    int device = 0, max_batch = 0, max_w = 0, max_h = 0;
+    Geo geo{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint8_t* d_planes = nullptr;
+    uint8_t* d_src = nullptr;
+    size_t src_slot = 0;
+    ImgDesc* d_desc = nullptr;
+    ImgDesc* h_desc = nullptr;
+    int* d_flags = nullptr;      // [2][HYST_MAX_PASSES]
+    int* h_flags = nullptr;      // [2] last-pass flags
+    unsigned* d_cent_list = nullptr;
+    int* d_counts = nullptr;     // cent_count | est_count | vcount | overflow
+    unsigned long long* d_est_keys = nullptr;
+    float* d_vcirc = nullptr;
+    int* d_lacc = nullptr;
+    int lrow = 0;
+    i2s_result* d_res = nullptr;
+    i2s_board* d_boards = nullptr;
+    i2s_board* h_boards = nullptr;
+    int* d_dbg_acc = nullptr;
+    int debug = 0;
+    int hyst_passes = 12;
+    int last_nb = 0;
+    HoughTrig last_trig{};
+    float timing[5] = {0, 0, 0, 0, 0};
+    char err[256] = {0};
+};
+
+#define I2S_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            snprintf(ctx->err, sizeof(ctx->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                               \
+            return I2S_E_HIP;                                                                           \
+        }                                                                                               \
+    } while (0)
+
+static inline uint8_t* plane_ptr(i2s_ctx* ctx, int plane) { return ctx->d_planes + (size_t)plane * ctx->geo.nb * ctx->geo.slot; }
+static inline int* cent_count(i2s_ctx* c) { return c->d_counts; }
+static inline int* est_count(i2s_ctx* c) { return c->d_counts + (size_t)c->max_batch * NVAR; }
+static inline int* vcount(i2s_ctx* c) { return c->d_counts + (size_t)2 * c->max_batch * NVAR; }
+static inline int* overflow(i2s_ctx* c) { return c->d_counts + (size_t)3 * c->max_batch * NVAR; }
+static inline size_t counts_bytes(i2s_ctx* c) { return ((size_t)3 * c->max_batch * NVAR + c->max_batch) * sizeof(int); }
+
+extern "C" int i2s_abi_version(void) { return I2S_ABI_VERSION; }
+
+extern "C" void i2s_default_params(i2s_params* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->canny_lo = 50; p->canny_hi = 200;
+    p->hc_min_dist = 10.f; p->hc_param1 = 100; p->hc_param2 = 30; p->hc_min_radius = 1; p->hc_max_radius = 30;
+    p->line_threshold = 0; p->black_threshold = 128;
+    p->align_x = I2S_ALIGN_LEFT; p->align_y = I2S_ALIGN_TOP;
+    p->min_grid_spacing = 10; p->big_space_ratio = 1.6; p->angle_tolerance_deg = 1.0;
+    p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 0; p->inputs_on_device = 0;
+}
+
+// choose_threshold (img2sgf.py:606-613)
+extern "C" int i2s_choose_threshold(int w, int h)
+{
+    const int x = w < h ? w : h;
+    int t = (int)(x / 12.8 + 16);
+    t = t < 20 ? 20 : (t > 200 ? 200 : t);
+    return t;
+}
+
+extern "C" const char* i2s_strerror(int code)
+{
+    switch (code) {
+        case I2S_OK: return "ok";
+        case I2S_E_INVALID: return "invalid argument";
+        case I2S_E_NO_DEVICE: return "no HIP device / device initialisation failed";
+        case I2S_E_HIP: return "HIP runtime error";
+        case I2S_E_TOO_LARGE: return "image larger than the context was created for";
+        case I2S_E_UNSUPPORTED: return "parameter outside the supported envelope";
+        default: return "unknown error";
+    }
+}
+
+extern "C" const char* i2s_last_error(const i2s_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" void i2s_destroy(i2s_ctx* ctx)
+{
+    if (!ctx) return;
+    void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc};
+    for (void* q : dev) if (q) (void)hipFree(q);
+    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards};
+    for (void* q : host) if (q) (void)hipHostFree(q);
+    for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static int create_impl(i2s_ctx* ctx)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || ctx->device >= ndev) return I2S_E_NO_DEVICE;
+    I2S_HIP(hipSetDevice(ctx->device));
+    I2S_HIP(hipStreamCreate(&ctx->stream));
+    for (int i = 0; i < 5; i++) I2S_HIP(hipEventCreate(&ctx->ev[i]));
+    Geo& g = ctx->geo;
+    g.pitch = (ctx->max_w + 63) / 64 * 64;
+    g.hmax = ctx->max_h;
+    g.wmax = ctx->max_w;
+    g.nb = ctx->max_batch;
+    g.slot = (long long)g.pitch * g.hmax;
+    const size_t nb = ctx->max_batch;
+    I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
+    ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
+    I2S_HIP(hipMalloc(&ctx->d_src, nb * ctx->src_slot + 256));
+    I2S_HIP(hipMalloc(&ctx->d_desc, nb * sizeof(ImgDesc)));
+    I2S_HIP(hipHostMalloc(&ctx->h_desc, nb * sizeof(ImgDesc)));
+    I2S_HIP(hipMalloc(&ctx->d_flags, 2 * HYST_MAX_PASSES * sizeof(int)));
+    I2S_HIP(hipHostMalloc(&ctx->h_flags, 2 * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * CENT_CAP * sizeof(unsigned)));
+    I2S_HIP(hipMalloc(&ctx->d_counts, counts_bytes(ctx)));
+    I2S_HIP(hipMalloc(&ctx->d_est_keys, nb * NVAR * EST_CAP * sizeof(unsigned long long)));
+    I2S_HIP(hipMalloc(&ctx->d_vcirc, nb * NVAR * VCIRC_CAP * 3 * sizeof(float)));
+    ctx->lrow = (2 * (ctx->max_w + ctx->max_h) + 1 + 15) / 16 * 16;
+    I2S_HIP(hipMalloc(&ctx->d_lacc, nb * LROWS * ctx->lrow * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_res, nb * sizeof(i2s_result)));
+    I2S_HIP(hipMalloc(&ctx->d_boards, nb * sizeof(i2s_board)));
+    I2S_HIP(hipHostMalloc(&ctx->h_boards, nb * sizeof(i2s_board)));
+    I2S_HIP(hipMemsetAsync(ctx->d_res, 0, nb * sizeof(i2s_result), ctx->stream));
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
+    return I2S_OK;
+}
+
+extern "C" int i2s_create(i2s_ctx** out, int device_id, int max_batch, int max_w, int max_h)
+{
+    if (!out || device_id < 0 || max_batch < 1 || max_batch > 4096 || max_w < 1 || max_h < 1 || max_w > 16384 || max_h > 16384)
+        return I2S_E_INVALID;
+    i2s_ctx* ctx = new i2s_ctx();
+    ctx->device = device_id; ctx->max_batch = max_batch; ctx->max_w = max_w; ctx->max_h = max_h;
+    const int rc = create_impl(ctx);
+    if (rc != I2S_OK) {
+        if (rc == I2S_E_HIP) fprintf(stderr, "i2s_create: %s\n", ctx->err);
+        i2s_destroy(ctx);
+        *out = nullptr;
+        return rc == I2S_E_HIP ? I2S_E_NO_DEVICE : rc;
+    }
+    *out = ctx;
+    return I2S_OK;
+}
+
+extern "C" int i2s_set_debug(i2s_ctx* ctx, int on)
+{
+    if (!ctx) return I2S_E_INVALID;
+    if (on && !ctx->d_dbg_acc)
+        I2S_HIP(hipMalloc(&ctx->d_dbg_acc, (size_t)ctx->max_batch * NVAR * ctx->geo.slot * sizeof(int)));
+    ctx->debug = on ? 1 : 0;
+    return I2S_OK;
+}
+
+// 8-bit fixed-point Gaussian taps (OpenCV getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED).
+static void gauss_taps(int k, double sigma, int mode, Taps* t)
+{
+    memset(t, 0, sizeof(*t));
+    const double sig = sigma > 0 ? sigma : ((k - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2x = -0.125 / (sig * sig);
+    const int n2 = (k - 1) / 2;
+    double vals[8], sum = 0, kern[8];
+    for (int i = 0, x = 1 - k; i < n2; i++, x += 2) { vals[i] = exp((double)(x * x) * scale2x); sum += vals[i]; }
+    sum = sum * 2 + 1.0;
+    const double mul = 1.0 / sum;
+    for (int i = 0; i < n2; i++) { kern[i] = vals[i] * mul; kern[k - 1 - i] = kern[i]; }
+    kern[n2] = mul;
+    if (mode == 1) { for (int i = 0; i < k; i++) t->k[i] = (int)lrint(kern[i] * 256.0); return; }
+    double err = 0; long s = 0;
+    for (int i = 0; i < n2; i++) {
+        const double adj = kern[i] * 256.0 + err;
+        const int v0 = (int)lrint(adj);
+        err = adj - (double)v0;
+        t->k[i] = v0; t->k[k - 1 - i] = v0; s += 2 * v0;
+    }
+    t->k[n2] = (int)(256 - s);
+}
+
+// numangle + trig tables of the three HoughLines calls of find_lines (img2sgf.py:236-244; hough.cpp
+// computeNumangle / createTrigTable; rho = 1 and theta = pi/180 narrowed to float by the C++ signature).
+static int hough_trig(const i2s_params* p, HoughTrig* t)
+{
+    const double PI = 3.14159265358979323846;   // math.pi == CV_PI
+    const double delta = PI / 180 * p->angle_tolerance_deg;
+    const float theta = (float)(PI / 180.0);
+    const double mins[3] = {PI / 2 - delta, 0.0, PI - delta};
+    const double maxs[3] = {PI / 2 + delta, delta, PI};
+    memset(t, 0, sizeof(*t));
+    for (int c = 0; c < 3; c++) {
+        int numangle;
+        if (p->houghlines_numangle_mode == 1) numangle = (int)lrint((maxs[c] - mins[c]) / theta);
+        else {
+            numangle = (int)floor((maxs[c] - mins[c]) / theta) + 1;
+            if (numangle > 1 && fabs(PI - (numangle - 1) * theta) < theta / 2) --numangle;
+        }
+        if (numangle < 0) numangle = 0;
+        if (numangle > LANG) return I2S_E_UNSUPPORTED;
+        t->n[c] = numangle;
+        float ang = (float)mins[c];
+        for (int n = 0; n < numangle; ang += theta, n++) {
+            t->sin_[c][n] = (float)(sin((double)ang) * 1.0f);
+            t->cos_[c][n] = (float)(cos((double)ang) * 1.0f);
+        }
+    }
+    return I2S_OK;
+}
+
+static int check_params(const i2s_params* p)
+{
+    if (!p) return I2S_E_INVALID;
+    if (p->hc_max_radius > 30 || p->hc_max_radius < 1 || p->hc_min_radius < 0 || p->hc_min_radius >= p->hc_max_radius)
+        return I2S_E_UNSUPPORTED;
+    if (p->hc_param2 < 0 || p->hc_param1 < 1 || p->canny_lo > p->canny_hi) return I2S_E_UNSUPPORTED;
+    if (p->grey_shift != 15 && p->grey_shift != 14) return I2S_E_UNSUPPORTED;
+    return I2S_OK;
+}
+
+static GridParams grid_params(const i2s_params* p)
+{
+    GridParams gp;
+    gp.min_grid_spacing = p->min_grid_spacing; gp.big_space_ratio = p->big_space_ratio;
+    gp.black_threshold = p->black_threshold; gp.align_x = p->align_x; gp.align_y = p->align_y; gp.pad = 0;
+    return gp;
+}
+
+static int run_hysteresis(i2s_ctx* ctx, int phase, int m_first, int nmaps, dim3 tiles)
+{
+    int* flags = ctx->d_flags + (size_t)phase * HYST_MAX_PASSES;
+    dim3 grid(tiles.x, tiles.y, ctx->geo.nb * nmaps);
+    for (int pass = 0; pass < ctx->hyst_passes; pass++)
+        hipLaunchKernelGGL(k_hysteresis, grid, dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, plane_ptr(ctx, I2S_PLANE_CANNY_MAP),
+                           m_first, flags, pass);
+    I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], flags + ctx->hyst_passes - 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return I2S_OK;
+}
+
+// One device pass over nb images whose descriptors are already in h_desc.
+static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool has_c3, const i2s_params* p,
+                    i2s_board* boards, i2s_result* full)
+{
+    Geo& g = ctx->geo;
+    g.nb = nb;
+    hipStream_t st = ctx->stream;
+    HoughTrig trig;
+    int rc = hough_trig(p, &trig);
+    if (rc) return rc;
+    ctx->last_trig = trig;
+    Taps t3, t5, t7;
+    gauss_taps(3, 3, p->gauss_kernel_mode, &t3);
+    gauss_taps(5, 5, p->gauss_kernel_mode, &t5);
+    gauss_taps(7, 7, p->gauss_kernel_mode, &t7);
+    const int hc_lo = p->hc_param1 / 2 > 1 ? p->hc_param1 / 2 : 1;
+    const GridParams gp = grid_params(p);
+
+    for (;;) {
+        I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
+        I2S_HIP(hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx), st));
+        I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, 2 * HYST_MAX_PASSES * sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
+        uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
+        uint8_t* map0 = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
+        const dim3 b64x4(64, 4), b256(256);
+        const dim3 g_row((wmax + 255) / 256, (hmax + 3) / 4, nb);
+        const dim3 g_f((wmax + FT_W - 1) / FT_W, (hmax + FT_H - 1) / FT_H, nb);
+        const dim3 g_h((wmax + HT - 1) / HT, (hmax + HT - 1) / HT, 1);
+
+        I2S_HIP(hipEventRecord(ctx->ev[0], st));
+        hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift);
+        hipLaunchKernelGGL((k_median<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3));
+        hipLaunchKernelGGL((k_gauss<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3), t3);
+        hipLaunchKernelGGL((k_median<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5));
+        hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5);
+        hipLaunchKernelGGL((k_median<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN7));
+        hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7);
+        if (has_c1) hipLaunchKernelGGL((k_sobel_nms_src<1>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi);
+        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi);
+        rc = run_hysteresis(ctx, 0, 0, 1, g_h);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES));
+        {
+            const dim3 g_v(g_f.x, g_f.y, nb * NVAR);
+            hipLaunchKernelGGL(k_sobel_nms_var, g_v, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot, 0, hc_lo, p->hc_param1);
+        }
+        rc = run_hysteresis(ctx, 1, 1, NVAR, g_h);
+        if (rc) return rc;
+        I2S_HIP(hipEventRecord(ctx->ev[1], st));
+
+        {
+            const dim3 g_vote((wmax + VT - 1) / VT, (hmax + VT - 1) / VT, nb * NVAR);
+            hipLaunchKernelGGL(k_vote_centres, g_vote, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
+                               p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                               ctx->debug ? ctx->d_dbg_acc : (int*)nullptr);
+            hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, map0 + (size_t)nb * g.slot,
+                               ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
+                               ctx->d_est_keys, est_count(ctx));
+            hipLaunchKernelGGL(k_circles_final, dim3(nb * NVAR), b256, 0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx),
+                               p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
+        }
+        I2S_HIP(hipEventRecord(ctx->ev[2], st));
+
+        hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res);
+        {
+            const dim3 g_e((wmax + ET_W - 1) / ET_W, (hmax + ET_H - 1) / ET_H, nb);
+            hipLaunchKernelGGL(k_erase_lines, g_e, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
+                               plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow);
+        }
+        hipLaunchKernelGGL(k_line_peaks, dim3(nb), b256, 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
+        I2S_HIP(hipEventRecord(ctx->ev[3], st));
+
+        hipLaunchKernelGGL(k_grid, dim3(nb), b256, 0, st, ctx->d_desc, g, grey, gp, 1, ctx->d_res, ctx->d_boards);
+        I2S_HIP(hipEventRecord(ctx->ev[4], st));
+
+        I2S_HIP(hipMemcpyAsync(ctx->h_boards, ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToHost, st));
+        if (full) I2S_HIP(hipMemcpyAsync(full, ctx->d_res, nb * sizeof(i2s_result), hipMemcpyDeviceToHost, st));
+        I2S_HIP(hipStreamSynchronize(st));
+        I2S_HIP(hipGetLastError());
+        if (ctx->h_flags[0] == 0 && ctx->h_flags[1] == 0) break;
+        // hysteresis had not reached its fixed point within the pass budget: redo this pass with more passes
+        if (ctx->hyst_passes >= HYST_MAX_PASSES) {
+            snprintf(ctx->err, sizeof(ctx->err), "Canny hysteresis did not converge in %d passes", HYST_MAX_PASSES);
+            return I2S_E_HIP;
+        }
+        ctx->hyst_passes = ctx->hyst_passes * 2 < HYST_MAX_PASSES ? ctx->hyst_passes * 2 : HYST_MAX_PASSES;
+    }
+    memcpy(boards, ctx->h_boards, nb * sizeof(i2s_board));
+    float ms;
+    for (int i = 0; i < 4; i++) {
+        I2S_HIP(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        ctx->timing[i] += ms;
+    }
+    I2S_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
+    ctx->timing[4] += ms;
+    ctx->last_nb = nb;
+    return I2S_OK;
+}
+
+extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, const int* w, const int* h,
+                                const int* stride, const int* channels, const i2s_params* p,
+                                i2s_board* boards, i2s_result* full)
+{
+    if (!ctx || B < 0 || (B > 0 && (!img || !w || !h || !stride || !channels || !boards))) return I2S_E_INVALID;
+    int rc = check_params(p);
+    if (rc) return rc;
+    for (int i = 0; i < B; i++) {
+        if (!img[i] || w[i] < 1 || h[i] < 1 || (channels[i] != 1 && channels[i] != 3) || stride[i] < w[i] * channels[i])
+            return I2S_E_INVALID;
+        if (w[i] > ctx->max_w || h[i] > ctx->max_h) return I2S_E_TOO_LARGE;
+    }
+    I2S_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < 5; i++) ctx->timing[i] = 0;
+    for (int first = 0; first < B; first += ctx->max_batch) {
+        const int nb = B - first < ctx->max_batch ? B - first : ctx->max_batch;
+        int wmax = 0, hmax = 0;
+        bool c1 = false, c3 = false;
+        for (int i = 0; i < nb; i++) {
+            const int k = first + i;
+            ImgDesc& d = ctx->h_desc[i];
+            d.w = w[k]; d.h = h[k]; d.cn = channels[k]; d.pad = 0;
+            d.line_thr = p->line_threshold > 0 ? p->line_threshold : i2s_choose_threshold(w[k], h[k]);
+            if (p->inputs_on_device) { d.src = img[k]; d.sstride = stride[k]; }
+            else {
+                uint8_t* dst = ctx->d_src + (size_t)i * ctx->src_slot;
+                const size_t rowb = (size_t)w[k] * channels[k];
+                I2S_HIP(hipMemcpy2DAsync(dst, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k], hipMemcpyHostToDevice, ctx->stream));
+                d.src = dst; d.sstride = (int)rowb;
+            }
+            wmax = w[k] > wmax ? w[k] : wmax; hmax = h[k] > hmax ? h[k] : hmax;
+            c1 |= channels[k] == 1; c3 |= channels[k] == 3;
+        }
+        rc = run_pass(ctx, nb, wmax, hmax, c1, c3, p, boards + first, full ? full + first : nullptr);
+        if (rc) return rc;
+    }
+    return I2S_OK;
+}
+
+extern "C" int i2s_classify_batch(i2s_ctx* ctx, int first, int n, const i2s_params* p, i2s_board* boards, i2s_result* full)
+{
+    if (!ctx || !p || !boards || first < 0 || n < 1 || first + n > ctx->last_nb) return I2S_E_INVALID;
+    I2S_HIP(hipSetDevice(ctx->device));
+    const GridParams gp = grid_params(p);
+    hipLaunchKernelGGL(k_grid, dim3(n), dim3(256), 0, ctx->stream, ctx->d_desc + first, ctx->geo,
+                       plane_ptr(ctx, I2S_PLANE_GREY) + (size_t)first * ctx->geo.slot, gp, 0, ctx->d_res + first, ctx->d_boards + first);
+    I2S_HIP(hipMemcpyAsync(boards, ctx->d_boards + first, n * sizeof(i2s_board), hipMemcpyDeviceToHost, ctx->stream));
+    if (full) I2S_HIP(hipMemcpyAsync(full, ctx->d_res + first, n * sizeof(i2s_result), hipMemcpyDeviceToHost, ctx->stream));
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
+    I2S_HIP(hipGetLastError());
+    return I2S_OK;
+}
+
+extern "C" int i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int h, const float* circles, int n_circles,
+                                   const float* hlines, int n_h, const float* vlines, int n_v, const i2s_params* p,
+                                   i2s_board* board, i2s_result* full)
+{
+    if (!ctx || !grey || !p || !board || w < 1 || h < 1 || n_circles < 0 || n_h < 0 || n_v < 0) return I2S_E_INVALID;
+    if (w > ctx->max_w || h > ctx->max_h) return I2S_E_TOO_LARGE;
+    if (n_circles > I2S_MAX_CIRCLES || n_h > I2S_MAX_LINES || n_v > I2S_MAX_LINES) return I2S_E_UNSUPPORTED;
+    I2S_HIP(hipSetDevice(ctx->device));
+    Geo& g = ctx->geo;
+    g.nb = 1;
+    hipStream_t st = ctx->stream;
+    i2s_result* hr = (i2s_result*)calloc(1, sizeof(i2s_result));
+    if (!hr) return I2S_E_INVALID;
+    hr->n_circles = n_circles; hr->n_hlines = n_h; hr->n_vlines = n_v;
+    hr->line_threshold = p->line_threshold > 0 ? p->line_threshold : i2s_choose_threshold(w, h);
+    if (n_circles) memcpy(hr->circles, circles, (size_t)n_circles * 3 * sizeof(float));
+    if (n_h) memcpy(hr->hlines, hlines, (size_t)n_h * sizeof(float));
+    if (n_v) memcpy(hr->vlines, vlines, (size_t)n_v * sizeof(float));
+    ImgDesc& d = ctx->h_desc[0];
+    d.src = nullptr; d.w = w; d.h = h; d.sstride = w; d.cn = 1; d.line_thr = hr->line_threshold; d.pad = 0;
+    hipError_t e1 = hipMemcpyAsync(ctx->d_desc, ctx->h_desc, sizeof(ImgDesc), hipMemcpyHostToDevice, st);
+    hipError_t e2 = hipMemcpyAsync(ctx->d_res, hr, sizeof(i2s_result), hipMemcpyHostToDevice, st);
+    hipError_t e3 = hipMemcpy2DAsync(plane_ptr(ctx, I2S_PLANE_GREY), g.pitch, grey, w, w, h, hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(256), 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GREY), grid_params(p), 1,
+                       ctx->d_res, ctx->d_boards);
+    hipError_t e4 = hipMemcpyAsync(board, ctx->d_boards, sizeof(i2s_board), hipMemcpyDeviceToHost, st);
+    hipError_t e5 = full ? hipMemcpyAsync(full, ctx->d_res, sizeof(i2s_result), hipMemcpyDeviceToHost, st) : hipSuccess;
+    hipError_t e6 = hipStreamSynchronize(st);
+    free(hr);
+    I2S_HIP(e1); I2S_HIP(e2); I2S_HIP(e3); I2S_HIP(e4); I2S_HIP(e5); I2S_HIP(e6);
+    I2S_HIP(hipGetLastError());
+    ctx->last_nb = 1;
+    return I2S_OK;
+}
+
+extern "C" int i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* dst, size_t dst_stride)
+{
+    if (!ctx || !dst || index < 0 || index >= ctx->last_nb || plane_id < 0 || plane_id >= NPLANES) return I2S_E_INVALID;
+    const ImgDesc& d = ctx->h_desc[index];
+    if (dst_stride < (size_t)d.w) return I2S_E_INVALID;
+    const uint8_t* src = plane_ptr(ctx, plane_id) + (size_t)index * ctx->geo.slot;
+    I2S_HIP(hipMemcpy2DAsync(dst, dst_stride, src, ctx->geo.pitch, d.w, d.h, hipMemcpyDeviceToHost, ctx->stream));
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
+    return I2S_OK;
+}
+
+extern "C" int i2s_last_timing(const i2s_ctx* ctx, float ms[5])
+{
+    if (!ctx || !ms) return I2S_E_INVALID;
+    for (int i = 0; i < 5; i++) ms[i] = ctx->timing[i];
+    return I2S_OK;
+}
+
+extern "C" int i2s_fetch_circle_acc(i2s_ctx* ctx, int index, int variant, int32_t* dst)
+{
+    if (!ctx || !dst || !ctx->d_dbg_acc || index < 0 || index >= ctx->last_nb || variant < 0 || variant >= NVAR) return I2S_E_INVALID;
+    const ImgDesc& d = ctx->h_desc[index];
+    const int* src = ctx->d_dbg_acc + ((size_t)index * NVAR + variant) * ctx->geo.hmax * ctx->geo.pitch;
+    I2S_HIP(hipMemcpy2DAsync(dst, (size_t)d.w * 4, src, (size_t)ctx->geo.pitch * 4, (size_t)d.w * 4, d.h, hipMemcpyDeviceToHost, ctx->stream));
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
+    return I2S_OK;
+}
+
+extern "C" int i2s_fetch_line_acc(i2s_ctx* ctx, int index, int32_t* dst, size_t cap, int* numrho, int* nangles)
+{
+    if (!ctx || !dst || index < 0 || index >= ctx->last_nb) return I2S_E_INVALID;
+    const ImgDesc& d = ctx->h_desc[index];
+    const int nr = 2 * (d.w + d.h) + 1;
+    if (cap < (size_t)LROWS * nr) return I2S_E_INVALID;
+    const int* src = ctx->d_lacc + (size_t)index * LROWS * ctx->lrow;
+    I2S_HIP(hipMemcpy2DAsync(dst, (size_t)nr * 4, src, (size_t)ctx->lrow * 4, (size_t)nr * 4, LROWS, hipMemcpyDeviceToHost, ctx->stream));
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
+    if (numrho) *numrho = nr;
+    if (nangles) { nangles[0] = ctx->last_trig.n[0]; nangles[1] = ctx->last_trig.n[1]; nangles[2] = ctx->last_trig.n[2]; }
+    return I2S_OK;
+}

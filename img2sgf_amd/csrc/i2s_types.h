@@ -1,0 +1,65 @@
+// Shared device/host types of the board-detection library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/i2s.h"
+
+namespace i2s {
+
+// Distinct HoughCircles inputs ("variants") in blur-bank order (img2sgf.py:171-175):
+// 0 grey, 1 edges, 2 median3, 3 gauss3, 4 median5, 5 gauss5, 6 median7, 7 gauss7.
+// The bank's k=1 median and Gaussian are copies of grey, so slots 0, 2, 3 share variant 0.
+constexpr int NVAR = 8;
+constexpr int NSLOT = I2S_NSLOTS;
+constexpr int NMAP = 9;   // Canny maps: 0 = main Canny (50/200 on the source), 1+v = HoughCircles' internal Canny of variant v
+__device__ __host__ inline int slot_variant(int s)
+{
+    return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s - 2;
+}
+
+constexpr int CENT_CAP = 8192;   // accumulator local maxima per (image, variant)
+constexpr int EST_CAP = 4096;    // supported circle estimates per (image, variant)
+constexpr int VCIRC_CAP = 2048;  // circles kept per (image, variant) after the min-dist pass
+
+// Per-image descriptor (device array, one per image of the current pass).
+struct ImgDesc {
+    const uint8_t* src;   // source pixels (device), channels interleaved
+    int w, h;
+    int sstride;          // bytes per source row
+    int cn;               // 1 or 3
+    int line_thr;         // Hough-lines threshold for this image
+    int pad;
+};
+
+// Plane addressing: plane p of image b starts at base + (p * nb + b) * slot; rows are `pitch` bytes.
+struct Geo {
+    int pitch;            // bytes per plane row (multiple of 64)
+    int hmax;             // rows per plane slot
+    int nb;               // images in this pass
+    int wmax;
+    long long slot;       // pitch * hmax
+};
+
+struct Taps { int k[8]; };
+
+struct HoughTrig {        // tables of the three HoughLines calls of find_lines (img2sgf.py:236-244)
+    int n[3];             // number of angles: [0] horizontal, [1] vertical near 0, [2] vertical near pi
+    float sin_[3][4];
+    float cos_[3][4];
+};
+
+__device__ __host__ inline int imin(int a, int b) { return a < b ? a : b; }
+__device__ __host__ inline int imax(int a, int b) { return a > b ? a : b; }
+__device__ __host__ inline int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __host__ inline int iabs_(int v) { return v < 0 ? -v : v; }
+
+// BORDER_REFLECT_101 for any p (gfedcb|abcdefgh|gfedcba)
+__device__ __host__ inline int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; }
+    return p;
+}
+
+}  // namespace i2s

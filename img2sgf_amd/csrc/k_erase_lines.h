@@ -1,0 +1,229 @@
+// Circle erase (img2sgf.py:188-198) fused with the HoughLines accumulation (img2sgf.py:236-244, OpenCV
+// hough.cpp HoughLinesStandard), and the accumulator peak search (findLocalMaximums + sort).
+#pragma once
+#include "i2s_types.h"
+
+namespace i2s {
+
+constexpr int ET_W = 64;
+constexpr int ET_H = 32;
+constexpr int LB = 128;          // LDS histogram bins per (call, angle) per tile
+constexpr int LANG = 4;          // angle rows reserved per HoughLines call
+constexpr int LROWS = 3 * LANG;  // accumulator rows per image
+
+// Concatenate the per-variant circle lists into the reference's `circles` array order
+// (slots of the blur bank, img2sgf.py:171-186).  grid (nb), block 256.
+__global__ __launch_bounds__(256) void k_concat_circles(Geo g, const float* __restrict__ vcirc, const int* __restrict__ vcount,
+                                                        const int* __restrict__ overflow, i2s_result* __restrict__ res)
+{
+    __shared__ int s_off[NSLOT + 1];
+    const int b = blockIdx.x;
+    i2s_result* R = res + b;
+    if (threadIdx.x == 0) {
+        int o = 0;
+        for (int s = 0; s < NSLOT; s++) {
+            s_off[s] = o;
+            const int n = vcount[b * NVAR + slot_variant(s)];
+            R->n_per_slot[s] = n;
+            o += n;
+        }
+        s_off[NSLOT] = o;
+        const bool over = overflow[b] != 0 || o > I2S_MAX_CIRCLES;
+        R->status = over ? I2S_ST_CAPACITY : 0;
+        R->n_circles = over ? 0 : o;
+        if (over) s_off[NSLOT] = -1;
+    }
+    __syncthreads();
+    if (s_off[NSLOT] < 0) return;
+    for (int s = 0; s < NSLOT; s++) {
+        const int n = s_off[s + 1] - s_off[s];
+        const float* src = vcirc + (size_t)(b * NVAR + slot_variant(s)) * VCIRC_CAP * 3;
+        float* dst = &R->circles[s_off[s]][0];
+        for (int i = threadIdx.x; i < n * 3; i += 256) dst[i] = src[i];
+    }
+}
+
+// grid (tiles_x, tiles_y, nb), block 256, tile 64x32.
+// removed(p) = edges(p) if no circle's box covers p; else with i = the LAST circle whose box covers p:
+// 255 if p is on circle i's centre plus (cv.circle radius 1), else 0.  (Sequential draw order of
+// img2sgf.py:191-198 resolved per pixel: a later rectangle erases earlier dots; each plus lies in its own box.)
+// Every non-zero pixel then votes into the rho accumulators of the three HoughLines calls through an LDS
+// histogram that is flushed with one global atomic per touched bin.
+// lacc[(b * LROWS + c * LANG + n) * lrow + r], r = cvRound(x*cos + y*sin) + (numrho-1)/2, numrho = 2(w+h)+1.
+__global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__ desc, Geo g,
+                                                     const uint8_t* __restrict__ edges, uint8_t* __restrict__ removed,
+                                                     const i2s_result* __restrict__ res, HoughTrig trig,
+                                                     int* __restrict__ lacc, int lrow)
+{
+    __shared__ short s_box[256][4];
+    __shared__ int s_idx[256];
+    __shared__ int s_n;
+    __shared__ int s_hist[LROWS][LB];
+    __shared__ int s_rmin[LROWS];
+    const int b = blockIdx.z;
+    const int w = desc[b].w, h = desc[b].h;
+    const int x0 = blockIdx.x * ET_W, y0 = blockIdx.y * ET_H;
+    if (x0 >= w || y0 >= h) return;
+    const int tid = threadIdx.x;
+    const i2s_result* R = res + b;
+    const int nc = R->n_circles;
+    const int half = w + h;   // (numrho - 1) / 2
+    for (int i = tid; i < LROWS * LB; i += 256) (&s_hist[0][0])[i] = 0;
+    if (tid < LROWS) {
+        const int c = tid / LANG, n = tid % LANG;
+        int rmin = 0;
+        if (n < trig.n[c]) {
+            const int xs[2] = {x0, imin(x0 + ET_W, w) - 1}, ys[2] = {y0, imin(y0 + ET_H, h) - 1};
+            rmin = 0x7fffffff;
+            for (int i = 0; i < 4; i++) {
+                const float a = (float)xs[i & 1] * trig.cos_[c][n], bb = (float)ys[i >> 1] * trig.sin_[c][n];
+                rmin = imin(rmin, __float2int_rn(a + bb));
+            }
+        }
+        s_rmin[tid] = rmin;
+    }
+    int best[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) best[k] = -1;
+    for (int base = 0; base < nc; base += 256) {
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const int i = base + tid;
+        if (i < nc) {
+            const float xc = R->circles[i][0], yc = R->circles[i][1];
+            const float r = R->circles[i][2] + 2.0f;
+            const int bx0 = __float2int_rn(xc - r), by0 = __float2int_rn(yc - r);
+            const int bx1 = __float2int_rn(xc + r), by1 = __float2int_rn(yc + r);
+            const int lo_x = imin(bx0, bx1), hi_x = imax(bx0, bx1), lo_y = imin(by0, by1), hi_y = imax(by0, by1);
+            if (hi_x >= x0 && lo_x < x0 + ET_W && hi_y >= y0 && lo_y < y0 + ET_H) {
+                const int k = atomicAdd(&s_n, 1);
+                s_box[k][0] = (short)iclamp(lo_x, -32768, 32767); s_box[k][1] = (short)iclamp(hi_x, -32768, 32767);
+                s_box[k][2] = (short)iclamp(lo_y, -32768, 32767); s_box[k][3] = (short)iclamp(hi_y, -32768, 32767);
+                s_idx[k] = i;
+            }
+        }
+        __syncthreads();
+        const int n = s_n;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int p = tid + k * 256;
+            const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
+            int bst = best[k];
+            for (int j = 0; j < n; j++)
+                if (px >= s_box[j][0] && px <= s_box[j][1] && py >= s_box[j][2] && py <= s_box[j][3]) bst = imax(bst, s_idx[j]);
+            best[k] = bst;
+        }
+        __syncthreads();
+    }
+    if (nc == 0) __syncthreads();   // s_hist / s_rmin initialisation
+    const uint8_t* e = edges + (size_t)b * g.slot;
+    uint8_t* o = removed + (size_t)b * g.slot;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int p = tid + k * 256;
+        const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
+        if (px >= w || py >= h) continue;
+        uint8_t val;
+        if (best[k] >= 0) {
+            const int mx = __float2int_rn(R->circles[best[k]][0]), my = __float2int_rn(R->circles[best[k]][1]);
+            const bool plus = (px == mx && iabs_(py - my) <= 1) || (py == my && iabs_(px - mx) <= 1);
+            val = plus ? 255 : 0;
+        } else {
+            val = e[(size_t)py * g.pitch + px];
+        }
+        o[(size_t)py * g.pitch + px] = val;
+        if (val != 0) {
+            for (int c = 0; c < 3; c++)
+                for (int n = 0; n < trig.n[c]; n++) {
+                    const float a = (float)px * trig.cos_[c][n], bb = (float)py * trig.sin_[c][n];
+                    const int r = __float2int_rn(a + bb);
+                    const int row = c * LANG + n;
+                    const unsigned bin = (unsigned)(r - s_rmin[row]);
+                    if (bin < (unsigned)LB) atomicAdd(&s_hist[row][bin], 1);
+                    else atomicAdd(&lacc[((size_t)b * LROWS + row) * lrow + r + half], 1);
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < LROWS * LB; i += 256) {
+        const int row = i / LB, bin = i - row * LB;
+        const int cnt = s_hist[row][bin];
+        if (cnt) atomicAdd(&lacc[((size_t)b * LROWS + row) * lrow + s_rmin[row] + bin + half], cnt);
+    }
+}
+
+// Peaks of one HoughLines call (findLocalMaximums + std::sort(hough_cmp_gt)), appended to out[] as rho.
+// Runs inside a 256-thread block; s_key is LDS scratch of I2S_MAX_LINES entries.  Returns the count (or -1
+// on overflow) in *s_cnt after the final __syncthreads().
+__device__ __forceinline__ void lines_peaks_call(const int* __restrict__ acc /* call base: LANG rows */, int lrow, int numrho,
+                                                 int numangle, int threshold, bool negate, unsigned long long* s_key,
+                                                 int* s_cnt, float* __restrict__ out, int out_base)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < numrho * numangle; i += 256) {
+        const int r = i / numangle, n = i - r * numangle;
+        const int a = acc[n * lrow + r];
+        if (a <= threshold) continue;
+        const int left = r > 0 ? acc[n * lrow + r - 1] : 0;
+        const int right = r < numrho - 1 ? acc[n * lrow + r + 1] : 0;
+        const int up = n > 0 ? acc[(n - 1) * lrow + r] : 0;
+        const int down = n < numangle - 1 ? acc[(n + 1) * lrow + r] : 0;
+        if (a > left && a >= right && a > up && a >= down) {
+            const int k = atomicAdd(s_cnt, 1);
+            const unsigned idx = (unsigned)((n + 1) * (numrho + 2) + r + 1);   // OpenCV's padded index: the sort tie-break
+            if (k < I2S_MAX_LINES) s_key[k] = ((unsigned long long)(0x7fffffffu - (unsigned)a) << 32) | idx;
+        }
+    }
+    __syncthreads();
+    const int cnt = *s_cnt;
+    if (cnt > I2S_MAX_LINES) { __syncthreads(); if (tid == 0) *s_cnt = -1; __syncthreads(); return; }
+    for (int i = tid; i < cnt; i += 256) {
+        const unsigned long long k = s_key[i];
+        int rank = 0;
+        for (int j = 0; j < cnt; j++) rank += (s_key[j] < k) ? 1 : 0;   // keys are unique (idx)
+        const int idx = (int)(k & 0xffffffffu);
+        const int n = idx / (numrho + 2) - 1;
+        const int r = idx - (n + 1) * (numrho + 2) - 1;
+        const float rho = ((float)r - (float)(numrho - 1) * 0.5f) * 1.0f;
+        if (out_base + rank < I2S_MAX_LINES) out[out_base + rank] = negate ? -rho : rho;
+    }
+    __syncthreads();
+}
+
+// find_all_lines (img2sgf.py:258-265): hlines from call 0; vlines = [call 1 ; call 2 with rho negated] (245-251).
+// grid (nb), block 256.
+__global__ __launch_bounds__(256) void k_line_peaks(const ImgDesc* __restrict__ desc, const int* __restrict__ lacc, int lrow,
+                                                    HoughTrig trig, i2s_result* __restrict__ res)
+{
+    __shared__ unsigned long long s_key[I2S_MAX_LINES];
+    __shared__ int s_cnt;
+    const int b = blockIdx.x;
+    i2s_result* R = res + b;
+    const int w = desc[b].w, h = desc[b].h, thr = desc[b].line_thr;
+    const int numrho = 2 * (w + h) + 1;
+    const int* acc = lacc + (size_t)b * LROWS * lrow;
+    bool over = false;
+    lines_peaks_call(acc, lrow, numrho, trig.n[0], thr, false, s_key, &s_cnt, R->hlines, 0);
+    const int nh = s_cnt;
+    __syncthreads();
+    lines_peaks_call(acc + (size_t)LANG * lrow, lrow, numrho, trig.n[1], thr, false, s_key, &s_cnt, R->vlines, 0);
+    const int nv1 = s_cnt;
+    __syncthreads();
+    over = nh < 0 || nv1 < 0;
+    int nv2 = 0;
+    if (!over) {
+        lines_peaks_call(acc + (size_t)2 * LANG * lrow, lrow, numrho, trig.n[2], thr, true, s_key, &s_cnt, R->vlines, nv1);
+        nv2 = s_cnt;
+        __syncthreads();
+        over = nv2 < 0 || nv1 + nv2 > I2S_MAX_LINES;
+    }
+    if (threadIdx.x == 0) {
+        R->line_threshold = thr;
+        if (over) { R->status = I2S_ST_CAPACITY; R->n_hlines = 0; R->n_vlines = 0; }
+        else { R->n_hlines = nh; R->n_vlines = nv1 + nv2; }
+    }
+}
+
+}  // namespace i2s

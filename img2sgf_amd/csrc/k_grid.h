@@ -1,0 +1,303 @@
+// find_grid() after the Hough transforms (img2sgf.py:546-576): clustering of the rho lists (268-292), grid
+// repair / validation (335-445), circle snapping (448-465), the mean-intensity stone classifier (468-543),
+// side-to-move guess and board alignment (484-494, 529-534).  One workgroup per image; the O(10^2) scalar
+// float64 logic runs on lane 0 with exactly the reference's operation order (Python float == IEEE double,
+// round() == rint), the window sums of the classifier run one wavefront per stone.
+#pragma once
+#include "i2s_types.h"
+
+namespace i2s {
+
+struct GridParams {
+    double min_grid_spacing, big_space_ratio;
+    int black_threshold, align_x, align_y, pad;
+};
+
+// img2sgf.py:400-417.  x[0..n) -> possibly shifted window; returns new length, *first = start offset.
+__device__ __host__ inline int truncate_grid(int n, int* first)
+{
+    if (n == I2S_BOARD_SIZE + 2) { *first += 1; return n - 2; }
+    if (n == I2S_BOARD_SIZE + 1) return n - 1;
+    return n;
+}
+
+// img2sgf.py:335-397.  in: x[0..n) sorted.  out: y[0..*m).  Returns 0 on success or an I2S_ST_H_* code
+// (caller adds the axis offset).  y may hold up to max(n, BOARD_SIZE + 3) values.
+__device__ __host__ inline int complete_grid(const double* x, int n, double* y, int* m, double min_spacing, double ratio)
+{
+    if (n == 0) return I2S_ST_H_NO_LINES;
+    if (n == 1) return I2S_ST_H_ONE_LINE;
+    double min_space = x[1] - x[0];
+    for (int i = 1; i < n - 1; i++) { const double s = x[i + 1] - x[i]; if (s < min_space) min_space = s; }
+    if (min_space < min_spacing) return I2S_ST_H_TOO_CLOSE;
+    const double bound = min_space * ratio;
+    int nbig = 0, nsmall = 0;
+    double max_space = 0;
+    bool have_small = false;
+    for (int i = 0; i < n - 1; i++) {
+        const double s = x[i + 1] - x[i];
+        if (s > bound) nbig++;
+        else { nsmall++; if (!have_small || s > max_space) { max_space = s; have_small = true; } }
+    }
+    if (nbig == 0) { for (int i = 0; i < n; i++) y[i] = x[i]; *m = n; return 0; }
+    const double average_space = (min_space + max_space) / 2;
+    int cnt = nsmall;
+    for (int i = 0; i < n - 1; i++) {
+        const double s = x[i + 1] - x[i];
+        if (s > bound) cnt += (int)rint(s / average_space);
+    }
+    if (cnt > I2S_BOARD_SIZE + 2) return I2S_ST_H_TOO_WIDE;
+    cnt += 1;
+    if (n < cnt) {
+        y[0] = x[0];
+        int i = 1, j = 1;
+        for (int q = 0; q < n - 1; q++) {
+            const double s = x[q + 1] - x[q];
+            if (s <= max_space) { y[i] = x[j]; i++; j++; }
+            else {
+                const int mm = (int)rint(s / average_space);
+                for (int k = 0; k < mm; k++) { y[i] = x[j - 1] + (double)(k + 1) * s / (double)mm; i++; }
+                j++;
+            }
+        }
+        *m = cnt;
+        return 0;
+    }
+    for (int i = 0; i < n; i++) y[i] = x[i];
+    *m = n;
+    return 0;
+}
+
+// img2sgf.py:448-459 with bisect_left.
+__device__ __host__ inline int closest_index(double a, const double* x, int n)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (x[mid] < a) lo = mid + 1; else hi = mid; }
+    const int i = lo;
+    if (i == 0) return 0;
+    if (i == n) return i - 1;
+    return (a - x[i - 1] <= x[i] - a) ? i - 1 : i;
+}
+
+// Sort-and-cluster of one rho list (find_clusters_fixed_threshold + get_cluster_centres, 268-292):
+// single linkage with distance_threshold d on a 1-D set == split the sorted values where the gap is >= d;
+// centre = float32 mean (sums of integer-valued rho are exact).  s_sorted: LDS scratch.  Whole block calls it.
+// Result in out[0..*n_out) (ascending), *n_out = -1 on capacity overflow.
+__device__ __forceinline__ void cluster_axis(const float* __restrict__ rho, int n, float* s_sorted, double min_spacing,
+                                             double* out, int* n_out)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) {
+        const float v = rho[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) { const float u = rho[j]; rank += (u < v || (u == v && j < i)) ? 1 : 0; }
+        s_sorted[rank] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int k = 0;
+        if (n >= 2) {
+            int start = 0;
+            for (int i = 1; i <= n; i++) {
+                if (i == n || (double)s_sorted[i] - (double)s_sorted[i - 1] >= min_spacing) {
+                    float sum = 0.f;
+                    for (int q = start; q < i; q++) sum += s_sorted[q];
+                    const float mean = sum / (float)(i - start);
+                    if (k < I2S_MAX_CENTRES) out[k] = (double)mean;
+                    k++;
+                    start = i;
+                }
+            }
+        }
+        *n_out = k > I2S_MAX_CENTRES ? -1 : k;
+    }
+    __syncthreads();
+}
+
+// grid (nb), block 256.  grey = variant plane 0.  Reads res[b].{circles, n_circles, hlines, vlines, status}
+// and fills the rest of res[b] and boards[b].  do_cluster = 0 re-runs only identify_board on the stored grid
+// (apply_black_thresh, img2sgf.py:762-766).
+__global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
+                                              GridParams gp, int do_cluster, i2s_result* __restrict__ res,
+                                              i2s_board* __restrict__ boards)
+{
+    __shared__ float s_sorted[I2S_MAX_LINES];
+    __shared__ double s_tmp[2][I2S_MAX_CENTRES + 4];
+    __shared__ int s_win[I2S_BOARD_SIZE * I2S_BOARD_SIZE][4];
+    __shared__ unsigned char s_det[I2S_BOARD_SIZE][I2S_BOARD_SIZE];
+    __shared__ int s_i[8];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int w = desc[b].w, h = desc[b].h;
+    i2s_result* R = res + b;
+    i2s_board* B = boards + b;
+    const bool capacity = R->status == I2S_ST_CAPACITY;
+    if (capacity) {
+        if (tid == 0) {
+            R->found_grid = R->valid_grid = R->board_ready = 0; R->hsize = R->vsize = 0;
+            R->n_hcentres = R->n_vcentres = R->n_hcomplete = R->n_vcomplete = 0;
+            R->n_stones = R->n_black = R->n_white = R->side_to_move = 0; R->n_circles_kept = 0;
+            for (int i = 0; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i++) (&B->board[0][0])[i] = 0;
+            B->status = I2S_ST_CAPACITY; B->side_to_move = 0; B->hsize = B->vsize = 0; B->found_grid = B->valid_grid = 0;
+            B->n_black = B->n_white = 0; B->n_circles = 0; B->line_threshold = (uint16_t)R->line_threshold;
+        }
+        return;
+    }
+    if (do_cluster) {
+        cluster_axis(R->hlines, R->n_hlines, s_sorted, gp.min_grid_spacing, R->hcentres, &s_i[0]);
+        cluster_axis(R->vlines, R->n_vlines, s_sorted, gp.min_grid_spacing, R->vcentres, &s_i[1]);
+        if (tid == 0) {
+            int status = 0;
+            const int nh = s_i[0], nv = s_i[1];
+            if (nh < 0 || nv < 0) status = I2S_ST_CAPACITY;
+            R->n_hcentres = nh < 0 ? 0 : nh; R->n_vcentres = nv < 0 ? 0 : nv;
+            R->found_grid = (nh > 0 && nv > 0) ? 1 : 0;
+            R->valid_grid = 0; R->board_ready = 0; R->hsize = 0; R->vsize = 0;
+            R->n_hcomplete = 0; R->n_vcomplete = 0; R->hspace = 0; R->vspace = 0;
+            int nck = R->n_circles;
+            for (int i = 0; i < R->n_circles; i++) R->circle_kept[i] = 1;   // validate_grid failure returns `circles` unfiltered (:426)
+            if (status == 0) {
+                // validate_grid (:420-445): horizontal lines first
+                int first = 0, m = 0;
+                int n = truncate_grid(nh, &first);
+                int rc = complete_grid(R->hcentres + first, n, s_tmp[0], &m, gp.min_grid_spacing, gp.big_space_ratio);
+                if (rc) status = rc;
+                else {
+                    int f2 = 0;
+                    const int mh = truncate_grid(m, &f2);
+                    for (int i = 0; i < mh; i++) R->hcentres_complete[i] = s_tmp[0][f2 + i];
+                    first = 0;
+                    n = truncate_grid(nv, &first);
+                    rc = complete_grid(R->vcentres + first, n, s_tmp[1], &m, gp.min_grid_spacing, gp.big_space_ratio);
+                    if (rc) status = rc + (I2S_ST_V_NO_LINES - I2S_ST_H_NO_LINES);
+                    else {
+                        f2 = 0;
+                        const int mv = truncate_grid(m, &f2);
+                        for (int i = 0; i < mv; i++) R->vcentres_complete[i] = s_tmp[1][f2 + i];
+                        const int vsize = mh, hsize = mv;    // number of horizontal lines = vertical size (:435-436)
+                        const double hspace = (R->hcentres_complete[mh - 1] - R->hcentres_complete[0]) / (double)vsize;
+                        const double vspace = (R->vcentres_complete[mv - 1] - R->vcentres_complete[0]) / (double)hsize;
+                        const double lo = (hspace < vspace ? hspace : vspace) * 0.3;
+                        const double hi = (hspace > vspace ? hspace : vspace) * 0.65;
+                        nck = 0;
+                        for (int i = 0; i < R->n_circles; i++) {
+                            const double r = (double)R->circles[i][2];
+                            const int keep = (lo < r && r < hi) ? 1 : 0;
+                            R->circle_kept[i] = (uint8_t)keep; nck += keep;
+                        }
+                        R->valid_grid = 1; R->vsize = vsize; R->hsize = hsize;
+                        R->n_hcomplete = mh; R->n_vcomplete = mv; R->hspace = hspace; R->vspace = vspace;
+                        if (hsize > I2S_BOARD_SIZE) status = I2S_ST_TOO_MANY_VLINES;
+                        else if (vsize > I2S_BOARD_SIZE) status = I2S_ST_TOO_MANY_HLINES;
+                    }
+                }
+            }
+            R->n_circles_kept = nck;
+            R->status = status;
+        }
+        __syncthreads();
+    }
+    // identify_board (:497-543)
+    const bool ready = R->valid_grid && R->hsize <= I2S_BOARD_SIZE && R->vsize <= I2S_BOARD_SIZE && R->status != I2S_ST_CAPACITY;
+    const int hsize = R->hsize, vsize = R->vsize;
+    for (int i = tid; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i += 256) (&s_det[0][0])[i] = 0;
+    __syncthreads();
+    if (ready) {
+        for (int i = tid; i < R->n_circles; i += 256) {
+            if (!R->circle_kept[i]) continue;
+            const int ci = closest_index((double)R->circles[i][0], R->vcentres_complete, hsize);
+            const int cj = closest_index((double)R->circles[i][1], R->hcentres_complete, vsize);
+            s_det[ci][cj] = I2S_STONE;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ns = 0;
+        if (ready) {
+            const double hspace = R->hspace, vspace = R->vspace;
+            for (int j = 0; j < hsize; j++)
+                for (int k = 0; k < vsize; k++)
+                    if (s_det[j][k] == I2S_STONE) {
+                        // average_intensity (:468-481); note x uses hspace, y uses vspace (reference quirk)
+                        const double x = R->vcentres_complete[j], y = R->hcentres_complete[k];
+                        int xmin = (int)rint(x - hspace / 2), xmax = (int)rint(x + hspace / 2);
+                        int ymin = (int)rint(y - vspace / 2), ymax = (int)rint(y + vspace / 2);
+                        xmin = imax(0, xmin); ymin = imax(0, ymin); xmax = imin(w, xmax); ymax = imin(h, ymax);
+                        s_win[ns][0] = xmin; s_win[ns][1] = xmax; s_win[ns][2] = ymin; s_win[ns][3] = ymax;
+                        ns++;
+                    }
+        }
+        s_i[2] = ns;
+    }
+    __syncthreads();
+    const int ns = s_i[2];
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const uint8_t* gp0 = grey + (size_t)b * g.slot;
+        for (int s0 = 0; s0 < ns; s0 += 4) {
+            const int s = s0 + wave;
+            unsigned sum = 0;
+            int cnt = 0;
+            if (s < ns) {
+                const int xmin = s_win[s][0], xmax = s_win[s][1], ymin = s_win[s][2], ymax = s_win[s][3];
+                const int bw = imax(xmax - xmin, 0), bh = imax(ymax - ymin, 0);
+                cnt = bw * bh;
+                for (int i = lane; i < cnt; i += 64) {
+                    const int yy = i / bw, xx = i - yy * bw;
+                    sum += gp0[(size_t)(ymin + yy) * g.pitch + xmin + xx];
+                }
+            }
+            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+            if (s < ns && lane == 0) {
+                // np.mean of uint8: float64 sum / count; empty slice -> nan (compares False -> WHITE)
+                R->brightness[s] = cnt > 0 ? (double)sum / (double)cnt : __builtin_nan("");
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nblack = 0;
+        const double thr = (double)gp.black_threshold;
+        if (ready) {
+            int s = 0;
+            for (int j = 0; j < hsize; j++)
+                for (int k = 0; k < vsize; k++)
+                    if (s_det[j][k] == I2S_STONE) {
+                        const bool black = R->brightness[s] <= thr;
+                        s_det[j][k] = black ? I2S_BLACK : I2S_WHITE;
+                        nblack += black ? 1 : 0;
+                        s++;
+                    }
+        }
+        const int nwhite = ns - nblack;
+        R->n_stones = ns; R->n_black = nblack; R->n_white = nwhite;
+        R->board_ready = ready ? 1 : 0;
+        R->side_to_move = ready ? (nblack <= nwhite ? 1 : 2) : 0;
+        s_i[3] = ready ? 1 : 0;
+    }
+    __syncthreads();
+    // align_board (:484-494) + publish
+    const int xoff = (gp.align_x == I2S_ALIGN_RIGHT) ? I2S_BOARD_SIZE - hsize : 0;
+    const int yoff = (gp.align_y == I2S_ALIGN_BOTTOM) ? I2S_BOARD_SIZE - vsize : 0;
+    for (int i = tid; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i += 256) {
+        const int bi = i / I2S_BOARD_SIZE, bj = i - bi * I2S_BOARD_SIZE;
+        uint8_t v = 0;
+        if (s_i[3]) {
+            const int di = bi - xoff, dj = bj - yoff;
+            if (di >= 0 && di < hsize && dj >= 0 && dj < vsize) v = s_det[di][dj];
+        }
+        R->board[bi][bj] = v;
+        B->board[bi][bj] = v;
+        R->detected[bi][bj] = (s_i[3] && bi < hsize && bj < vsize) ? s_det[bi][bj] : 0;
+    }
+    if (tid == 0) {
+        B->status = (uint8_t)R->status; B->side_to_move = (uint8_t)R->side_to_move;
+        B->hsize = (uint8_t)imin(R->hsize, 255); B->vsize = (uint8_t)imin(R->vsize, 255);
+        B->found_grid = (uint8_t)R->found_grid; B->valid_grid = (uint8_t)R->valid_grid; B->pad0 = 0;
+        B->n_black = (uint16_t)R->n_black; B->n_white = (uint16_t)R->n_white;
+        B->n_circles = (uint16_t)R->n_circles; B->line_threshold = (uint16_t)R->line_threshold;
+        for (int i = 0; i < 8; i++) B->pad[i] = 0;
+    }
+}
+
+}  // namespace i2s

@@ -1,0 +1,319 @@
+"""Host-side mirror of the reference's board-detection interface (img2sgf.py:103-596) on top of the HIP
+kernels.  Same function names as the reference, explicit arguments and return values instead of module
+globals; `Detection` carries exactly the globals the reference's GUI code reads afterwards.
+
+    det = process_image(input_image_np)            # img2sgf.py:117-204 + find_grid 546-576
+    det.circles, det.hcentres_complete, det.full_board, to_SGF(det.full_board, det.side_to_move) ...
+
+Everything numeric runs on the GPU through the C ABI (include/i2s.h); there is no CPU fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import I2sBoard, I2sError, I2sParams, I2sResult, PLANE_NAMES, STATUS_TEXT
+
+BOARD_SIZE = 19                       # img2sgf.py:43
+EMPTY, BLACK, WHITE, STONE = range(4)  # BoardStates, img2sgf.py:82-83
+TOP, BOTTOM, LEFT, RIGHT = range(4)    # Alignment, img2sgf.py:86-87
+
+
+@dataclass
+class Params:
+    """The reference's constants (img2sgf.py:43-57) and hard-wired OpenCV call arguments."""
+    canny_lo: int = 50                 # edge_min_default :47
+    canny_hi: int = 200                # edge_max_default :48
+    hc_min_dist: float = 10.0          # HoughCircles args :180
+    hc_param1: int = 100
+    hc_param2: int = 30
+    hc_min_radius: int = 1
+    hc_max_radius: int = 30
+    line_threshold: int = 0            # 0 -> choose_threshold(image) (:638)
+    black_threshold: int = 128         # black_stone_threshold_default :45
+    alignment: Sequence[int] = (LEFT, TOP)   # board_alignment :627
+    min_grid_spacing: float = 10       # :54
+    big_space_ratio: float = 1.6       # :55
+    angle_tolerance: float = 1.0       # :52 (degrees)
+    grey_shift: int = 15               # OpenCV-version switches
+    gauss_kernel_mode: int = 0
+    houghlines_numangle_mode: int = 0
+
+    def to_c(self, inputs_on_device=False):
+        p = I2sParams()
+        p.canny_lo, p.canny_hi = self.canny_lo, self.canny_hi
+        p.hc_min_dist = self.hc_min_dist
+        p.hc_param1, p.hc_param2 = self.hc_param1, self.hc_param2
+        p.hc_min_radius, p.hc_max_radius = self.hc_min_radius, self.hc_max_radius
+        p.line_threshold, p.black_threshold = self.line_threshold, self.black_threshold
+        p.align_x, p.align_y = int(self.alignment[0]), int(self.alignment[1])
+        p.min_grid_spacing, p.big_space_ratio = self.min_grid_spacing, self.big_space_ratio
+        p.angle_tolerance_deg = self.angle_tolerance
+        p.grey_shift, p.gauss_kernel_mode = self.grey_shift, self.gauss_kernel_mode
+        p.houghlines_numangle_mode = self.houghlines_numangle_mode
+        p.inputs_on_device = 1 if inputs_on_device else 0
+        return p
+
+
+@dataclass
+class Detection:
+    """What the reference leaves in its globals after process_image()."""
+    status: int
+    status_text: str
+    threshold: int
+    circles_all: np.ndarray            # `circles` after the HoughCircles loop (:186), float32 (n,3)
+    n_per_slot: List[int]
+    circles: np.ndarray                # after validate_grid's radius filter (:443)
+    hlines: np.ndarray                 # raw rho lists from find_all_lines (:258-265)
+    vlines: np.ndarray
+    hcentres: np.ndarray
+    vcentres: np.ndarray
+    found_grid: bool
+    valid_grid: bool
+    board_ready: bool
+    hsize: int
+    vsize: int
+    hcentres_complete: Optional[np.ndarray]
+    vcentres_complete: Optional[np.ndarray]
+    hspace: Optional[float]
+    vspace: Optional[float]
+    detected_board: Optional[np.ndarray]   # (hsize, vsize)
+    full_board: Optional[np.ndarray]       # (19, 19), [column, row]
+    stone_brightnesses: np.ndarray
+    num_black_stones: int
+    num_white_stones: int
+    side_to_move: int                  # 1 black, 2 white (img2sgf.py:89)
+    planes: dict = field(default_factory=dict)   # optional: grey / edges / removed numpy images
+
+    @property
+    def sgf(self):
+        return to_SGF(self.full_board, self.side_to_move) if self.board_ready else None
+
+
+def _detection_from_result(r: I2sResult) -> Detection:
+    n = r.n_circles
+    circ = np.ctypeslib.as_array(r.circles)[:n].copy()
+    kept = np.ctypeslib.as_array(r.circle_kept)[:n].astype(bool)
+    valid = bool(r.valid_grid)
+    ready = bool(r.board_ready)
+    hs, vs = r.hsize, r.vsize
+    full = np.ctypeslib.as_array(r.board).astype(np.float64).copy() if ready else None
+    det = np.ctypeslib.as_array(r.detected)[:hs, :vs].astype(np.float64).copy() if ready else None
+    return Detection(
+        status=r.status, status_text=STATUS_TEXT.get(r.status, "?"), threshold=r.line_threshold,
+        circles_all=circ, n_per_slot=list(r.n_per_slot), circles=circ[kept] if valid else circ,
+        hlines=np.ctypeslib.as_array(r.hlines)[:r.n_hlines].copy(),
+        vlines=np.ctypeslib.as_array(r.vlines)[:r.n_vlines].copy(),
+        hcentres=np.ctypeslib.as_array(r.hcentres)[:r.n_hcentres].copy(),
+        vcentres=np.ctypeslib.as_array(r.vcentres)[:r.n_vcentres].copy(),
+        found_grid=bool(r.found_grid), valid_grid=valid, board_ready=ready, hsize=hs, vsize=vs,
+        hcentres_complete=np.ctypeslib.as_array(r.hcentres_complete)[:r.n_hcomplete].copy() if valid else None,
+        vcentres_complete=np.ctypeslib.as_array(r.vcentres_complete)[:r.n_vcomplete].copy() if valid else None,
+        hspace=r.hspace if valid else None, vspace=r.vspace if valid else None,
+        detected_board=det, full_board=full,
+        stone_brightnesses=np.ctypeslib.as_array(r.brightness)[:r.n_stones].copy() if ready else np.zeros(0),
+        num_black_stones=r.n_black, num_white_stones=r.n_white, side_to_move=r.side_to_move)
+
+
+class Detector:
+    """One GPU context (one HIP stream on one device).  max_batch = images per device pass."""
+
+    def __init__(self, device=0, max_batch=16, max_w=1024, max_h=1024, lib=None):
+        self.lib = lib if lib is not None else _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self.lib.dll.i2s_create(C.byref(self._ctx), device, max_batch, max_w, max_h)
+        if rc != 0:
+            raise I2sError("i2s_create failed: %s (no CPU fallback exists)" % self.lib.dll.i2s_strerror(rc).decode())
+        self.max_batch, self.max_w, self.max_h = max_batch, max_w, max_h
+        self._last_shapes = []
+
+    def close(self):
+        if self._ctx:
+            self.lib.dll.i2s_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise I2sError("%s: %s" % (self.lib.dll.i2s_strerror(rc).decode(),
+                                       self.lib.dll.i2s_last_error(self._ctx).decode()))
+
+    # -- raw entry: pointers may be host (numpy) or device addresses
+    def detect_ptrs(self, ptrs, ws, hs, strides, chans, params: Params, on_device, full=False):
+        B = len(ptrs)
+        arr_p = (C.c_void_p * B)(*[int(p) for p in ptrs])
+        mk = lambda v: (C.c_int * B)(*[int(x) for x in v])
+        boards = (I2sBoard * B)()
+        res = (I2sResult * B)() if full else None
+        p = params.to_c(on_device)
+        rc = self.lib.dll.i2s_detect_batch(self._ctx, B, arr_p, mk(ws), mk(hs), mk(strides), mk(chans), C.byref(p),
+                                           boards, res)
+        self._check(rc)
+        self._last_shapes = list(zip(hs, ws))[-((B - 1) % self.max_batch + 1):]
+        return boards, res
+
+    def detect_batch(self, images: Sequence[np.ndarray], params: Optional[Params] = None, full=True):
+        """images: HxW (grey) or HxWx3 uint8 arrays = the reference's `input_image_np` (img2sgf.py:150).
+        Returns a list of Detection (full=True) or the raw I2sBoard array (full=False)."""
+        params = params or Params()
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            if im.ndim not in (2, 3) or (im.ndim == 3 and im.shape[2] != 3):
+                raise ValueError("images must be HxW or HxWx3 uint8")
+        boards, res = self.detect_ptrs([im.ctypes.data for im in imgs], [im.shape[1] for im in imgs],
+                                       [im.shape[0] for im in imgs], [im.strides[0] for im in imgs],
+                                       [1 if im.ndim == 2 else 3 for im in imgs], params, False, full)
+        if not full:
+            return boards
+        return [_detection_from_result(r) for r in res]
+
+    def detect_device(self, batch, params: Optional[Params] = None):
+        """batch: a torch uint8 tensor (B,H,W) or (B,H,W,3) resident on this context's GPU.  Returns (B,) I2sBoard
+        array; the pixels are read in place (no copy)."""
+        params = params or Params()
+        assert batch.is_cuda and batch.is_contiguous() and str(batch.dtype) == "torch.uint8"
+        B, H, W = batch.shape[:3]
+        cn = 1 if batch.dim() == 3 else 3
+        base, step = batch.data_ptr(), H * W * cn
+        boards, _ = self.detect_ptrs([base + i * step for i in range(B)], [W] * B, [H] * B, [W * cn] * B, [cn] * B,
+                                     params, True, False)
+        return boards
+
+    def classify(self, first, n, params: Params, full=True):
+        """identify_board() only (apply_black_thresh, img2sgf.py:762-766) on images of the last device pass."""
+        boards = (I2sBoard * n)()
+        res = (I2sResult * n)() if full else None
+        p = params.to_c()
+        self._check(self.lib.dll.i2s_classify_batch(self._ctx, first, n, C.byref(p), boards, res))
+        return [_detection_from_result(r) for r in res] if full else boards
+
+    def grid_from_lines(self, grey, circles, hlines, vlines, params: Optional[Params] = None):
+        """find_grid() (img2sgf.py:546-576) on injected circles and rho lists."""
+        params = params or Params()
+        grey = np.ascontiguousarray(grey, np.uint8)
+        c = np.ascontiguousarray(circles, np.float32).reshape(-1, 3)
+        hl = np.ascontiguousarray(hlines, np.float32).reshape(-1)
+        vl = np.ascontiguousarray(vlines, np.float32).reshape(-1)
+        f32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+        board, res = I2sBoard(), I2sResult()
+        p = params.to_c()
+        self._check(self.lib.dll.i2s_grid_from_lines(
+            self._ctx, grey.ctypes.data_as(u8p), grey.shape[1], grey.shape[0], c.ctypes.data_as(f32p), len(c),
+            hl.ctypes.data_as(f32p), len(hl), vl.ctypes.data_as(f32p), len(vl), C.byref(p), C.byref(board),
+            C.byref(res)))
+        self._last_shapes = [grey.shape]
+        return _detection_from_result(res)
+
+    def fetch_plane(self, index, plane):
+        """numpy image of a device plane of the last pass: 'grey', 'edges', 'removed', 'median3', ... or an int id."""
+        pid = PLANE_NAMES[plane] if isinstance(plane, str) else int(plane)
+        h, w = self._last_shapes[index][:2]
+        out = np.empty((h, w), np.uint8)
+        self._check(self.lib.dll.i2s_fetch_plane(self._ctx, index, pid, out.ctypes.data_as(C.POINTER(C.c_uint8)), w))
+        return out
+
+    def set_debug(self, on=True):
+        self._check(self.lib.dll.i2s_set_debug(self._ctx, 1 if on else 0))
+
+    def fetch_circle_acc(self, index, variant):
+        h, w = self._last_shapes[index][:2]
+        out = np.empty((h, w), np.int32)
+        self._check(self.lib.dll.i2s_fetch_circle_acc(self._ctx, index, variant, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def fetch_line_acc(self, index):
+        h, w = self._last_shapes[index][:2]
+        nr = 2 * (w + h) + 1
+        out = np.zeros((12, nr), np.int32)
+        numrho, nang = C.c_int(0), (C.c_int * 3)()
+        self._check(self.lib.dll.i2s_fetch_line_acc(self._ctx, index, out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    out.size, C.byref(numrho), nang))
+        return out, list(nang)
+
+    def last_timing(self):
+        ms = (C.c_float * 5)()
+        self._check(self.lib.dll.i2s_last_timing(self._ctx, ms))
+        return dict(blur_canny_ms=ms[0], hough_circles_ms=ms[1], erase_lines_ms=ms[2], grid_ms=ms[3], total_ms=ms[4])
+
+
+_default_detector = None
+
+
+def _detector_for(images, detector):
+    global _default_detector
+    if detector is not None:
+        return detector
+    hmax = max(im.shape[0] for im in images)
+    wmax = max(im.shape[1] for im in images)
+    d = _default_detector
+    if d is None or d.max_w < wmax or d.max_h < hmax:
+        if d is not None:
+            d.close()
+        d = _default_detector = Detector(0, 8, max(wmax, 1024), max(hmax, 1024))
+    return d
+
+
+# ---- the reference's entry points (same names) ---------------------------------------------------------
+
+def choose_threshold(img):
+    """img2sgf.py:606-613.  img: PIL image, numpy image or (w, h)."""
+    if hasattr(img, "size") and not isinstance(img, np.ndarray):
+        w, h = img.size
+    elif isinstance(img, np.ndarray):
+        h, w = img.shape[:2]
+    else:
+        w, h = img
+    return _lib.load().dll.i2s_choose_threshold(int(w), int(h))
+
+
+def process_image(input_image_np, params: Optional[Params] = None, detector: Optional[Detector] = None,
+                  keep_planes=False) -> Detection:
+    """img2sgf.py:117-204 from `input_image_np` (:150) on, including find_grid() (:546-576)."""
+    d = _detector_for([input_image_np], detector)
+    det = d.detect_batch([input_image_np], params, full=True)[0]
+    if keep_planes:
+        det.planes = {k: d.fetch_plane(0, k) for k in ("grey", "edges", "removed")}
+    return det
+
+
+def identify_board(detector: Detector, index=0, black_threshold=128, alignment=(LEFT, TOP)) -> Detection:
+    """img2sgf.py:497-543 re-run on a cached detection (what apply_black_thresh does, :762-766)."""
+    return detector.classify(index, 1, Params(black_threshold=black_threshold, alignment=alignment))[0]
+
+
+def find_grid(grey, circles, hlines, vlines, params: Optional[Params] = None, detector: Optional[Detector] = None):
+    """img2sgf.py:546-576 with find_lines' outputs injected."""
+    d = _detector_for([grey], detector)
+    return d.grid_from_lines(grey, circles, hlines, vlines, params)
+
+
+def to_SGF(board, side_to_move):
+    """img2sgf.py:781-810, byte for byte."""
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    board = np.asarray(board)
+    out = "(;GM[1]FF[4]SZ[" + str(BOARD_SIZE) + "]\n"
+    out += "PL[B]\n" if side_to_move == 1 else "PL[W]\n"
+    black_moves, white_moves = "", ""
+    if (board == BLACK).any():
+        black_moves = "AB" + "".join("[" + letters[i] + letters[j] + "]" for i in range(BOARD_SIZE)
+                                     for j in range(BOARD_SIZE) if board[i, j] == BLACK)
+    if (board == WHITE).any():
+        white_moves = "AW" + "".join("[" + letters[i] + letters[j] + "]" for i in range(BOARD_SIZE)
+                                     for j in range(BOARD_SIZE) if board[i, j] == WHITE)
+    if side_to_move == 1:
+        return out + black_moves + "\n" + white_moves + "\n" + ")\n"
+    return out + white_moves + "\n" + black_moves + "\n" + ")\n"
+
+
+def board_to_sgf(b: I2sBoard):
+    """SGF text of a compact board record (None when no board was produced)."""
+    if b.status != 0:
+        return None
+    return to_SGF(np.ctypeslib.as_array(b.board), b.side_to_move)

@@ -1,0 +1,200 @@
+/*
+ * i2s.h -- C ABI of the MI355X board-detection library (libi2s_hip.so).
+ *
+ * The reference (hanysz/img2sgf) has no FFI: its hot path is wired through Python module
+ * globals and direct cv2 calls.  This header is the boundary a maintainer binds with ctypes
+ * (INTEGRATION.md shows the stub).  Each entry point names the reference interface it
+ * replaces (file:line in img2sgf.py):
+ *
+ *   i2s_detect_batch      process_image() 117-204 + find_grid() 546-576 for a batch of images:
+ *                         cv.cvtColor 153, cv.Canny 162, cv.medianBlur 174, cv.GaussianBlur 175,
+ *                         10x cv.HoughCircles 180, rectangle/circle erase 191-198,
+ *                         find_all_lines/find_lines 230-265 (3x cv.HoughLines),
+ *                         cluster_lines 295-332, validate_grid 420-445, identify_board 497-543.
+ *   i2s_classify_batch    apply_black_thresh() 762-766 -> identify_board() 497-543 only
+ *                         (re-classify cached detections with a new black threshold / alignment).
+ *   i2s_grid_from_lines   find_grid() 546-576 with injected circles and Hough-line rho lists
+ *                         (what find_grid sees after find_lines 230-255 returned).
+ *   i2s_choose_threshold  choose_threshold() 606-613.
+ *   i2s_fetch_plane       the numpy images the GUI draws: grey_image_np 153,
+ *                         edge_detected_image_np 162, the blur bank 171-175,
+ *                         circles_removed_image_np 169-198.
+ *
+ * Conventions: plain pointers and sizes, no C++ types; all functions return 0 (I2S_OK) or a
+ * negative I2S_E_* code and never throw; caller owns every buffer passed in; the context
+ * owns all device memory; a context is single-caller (the reference is single-threaded) and
+ * calls are synchronous on return.  There is NO CPU fallback: i2s_create fails with
+ * I2S_E_NO_DEVICE when no gfx950 GPU is visible.
+ */
+#ifndef I2S_H
+#define I2S_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2S_ABI_VERSION 1
+
+#define I2S_BOARD_SIZE 19      /* img2sgf.py:43 */
+#define I2S_NSLOTS 10          /* blur-bank slots, img2sgf.py:171-175 */
+#define I2S_MAX_CIRCLES 4096   /* concatenated circles per image (all 10 slots) */
+#define I2S_MAX_LINES 1024     /* Hough-line peaks per direction */
+#define I2S_MAX_CENTRES 256    /* cluster centres / completed grid lines per direction */
+
+/* return codes */
+enum {
+    I2S_OK = 0,
+    I2S_E_INVALID = -1,      /* bad argument */
+    I2S_E_NO_DEVICE = -2,    /* no MI355X visible / HIP runtime error at create */
+    I2S_E_HIP = -3,          /* HIP runtime error during a call (see i2s_last_error) */
+    I2S_E_TOO_LARGE = -4,    /* image larger than the context was created for */
+    I2S_E_UNSUPPORTED = -5   /* parameter outside the supported envelope */
+};
+
+/* per-image status (i2s_board.status / i2s_result.status); mirrors the reference's log lines */
+enum {
+    I2S_ST_BOARD_READY = 0,        /* board_ready = True (img2sgf.py:574) */
+    I2S_ST_H_NO_LINES = 1,         /* "No grid lines found at all!" 340 (horizontal axis) */
+    I2S_ST_H_ONE_LINE = 2,         /* "Only found one grid line" 344 */
+    I2S_ST_H_TOO_CLOSE = 3,        /* "Grid lines are too close together" 351 */
+    I2S_ST_H_TOO_WIDE = 4,         /* "Distance between edges of grid is ..." 371 */
+    I2S_ST_V_NO_LINES = 5,
+    I2S_ST_V_ONE_LINE = 6,
+    I2S_ST_V_TOO_CLOSE = 7,
+    I2S_ST_V_TOO_WIDE = 8,
+    I2S_ST_TOO_MANY_VLINES = 9,    /* hsize > 19, "Too many vertical lines!" 569 */
+    I2S_ST_TOO_MANY_HLINES = 10,   /* vsize > 19, "Too many horizontal lines!" 571 */
+    I2S_ST_CAPACITY = 100          /* a fixed capacity (circles/lines/centres) overflowed: results invalid */
+};
+
+/* board cell values: BoardStates, img2sgf.py:82-83 */
+enum { I2S_EMPTY = 0, I2S_BLACK = 1, I2S_WHITE = 2, I2S_STONE = 3 };
+/* Alignment, img2sgf.py:86-87 */
+enum { I2S_ALIGN_TOP = 0, I2S_ALIGN_BOTTOM = 1, I2S_ALIGN_LEFT = 2, I2S_ALIGN_RIGHT = 3 };
+
+/* plane ids for i2s_fetch_plane */
+enum {
+    I2S_PLANE_GREY = 0,      /* grey_image_np */
+    I2S_PLANE_EDGES = 1,     /* edge_detected_image_np (0/255) */
+    I2S_PLANE_MEDIAN3 = 2, I2S_PLANE_GAUSS3 = 3,
+    I2S_PLANE_MEDIAN5 = 4, I2S_PLANE_GAUSS5 = 5,
+    I2S_PLANE_MEDIAN7 = 6, I2S_PLANE_GAUSS7 = 7,
+    I2S_PLANE_REMOVED = 8,   /* circles_removed_image_np */
+    I2S_PLANE_CANNY_MAP = 9, /* +m: Canny map m after hysteresis (2 = edge); m=0 main, 1..8 HoughCircles inputs */
+    I2S_PLANE__COUNT = 18
+};
+
+typedef struct i2s_ctx i2s_ctx;
+
+/* Parameters = the reference's constants (img2sgf.py:43-57) and hard-wired call arguments.
+ * i2s_default_params() fills in the reference's values. */
+typedef struct i2s_params {
+    int32_t canny_lo, canny_hi;        /* 50, 200            img2sgf.py:47-48, 162 */
+    float   hc_min_dist;               /* 10                 :180 */
+    int32_t hc_param1, hc_param2;      /* 100, 30            :180 */
+    int32_t hc_min_radius, hc_max_radius; /* 1, 30           :180  (max_radius <= 30 supported) */
+    int32_t line_threshold;            /* 0 = choose_threshold(w,h) per image (:638); else fixed */
+    int32_t black_threshold;           /* 128                :45 */
+    int32_t align_x, align_y;          /* I2S_ALIGN_LEFT, I2S_ALIGN_TOP  :627 */
+    double  min_grid_spacing;          /* 10                 :54 */
+    double  big_space_ratio;           /* 1.6                :55 */
+    double  angle_tolerance_deg;       /* 1.0                :52 */
+    /* OpenCV-version switches; defaults = current 4.x */
+    int32_t grey_shift;                /* 15 (4.x) | 14 (3.x) */
+    int32_t gauss_kernel_mode;         /* 0 = error-diffused taps summing to 256 | 1 = plain rounding */
+    int32_t houghlines_numangle_mode;  /* 0 = floor+1 with pi-wrap fix (current) | 1 = cvRound (legacy) */
+    int32_t inputs_on_device;          /* 1: img[] are device pointers (no copy); 0: host pointers */
+} i2s_params;
+
+/* Compact per-image record: what the SGF writer needs (to_SGF 781-810) and what ranks
+ * all-gather (384 bytes). board[i][j]: i = column (x), j = row (y), exactly full_board[i,j]. */
+typedef struct i2s_board {
+    uint8_t board[I2S_BOARD_SIZE][I2S_BOARD_SIZE];
+    uint8_t status;          /* I2S_ST_* */
+    uint8_t side_to_move;    /* 1 = black, 2 = white (img2sgf.py:89, 529-534); 0 if no board */
+    uint8_t hsize, vsize;    /* detected grid size */
+    uint8_t found_grid, valid_grid;
+    uint8_t pad0;
+    uint16_t n_black, n_white;
+    uint16_t n_circles;      /* concatenated circle count */
+    uint16_t line_threshold; /* Hough-lines threshold used */
+    uint8_t pad[8];
+} i2s_board;
+
+/* Full per-image record: every value the reference leaves in its globals for the GUI. */
+typedef struct i2s_result {
+    int32_t status;
+    int32_t line_threshold;
+    int32_t found_grid, valid_grid, board_ready;
+    int32_t hsize, vsize;
+    int32_t n_circles;                      /* `circles` after the HoughCircles loop (:186) */
+    int32_t n_per_slot[I2S_NSLOTS];         /* circles contributed by each blur-bank slot */
+    int32_t n_circles_kept;                 /* after validate_grid's radius filter (:443) */
+    int32_t n_hlines, n_vlines;             /* find_all_lines (:258-265) */
+    int32_t n_hcentres, n_vcentres;         /* cluster_lines (:295-332) */
+    int32_t n_hcomplete, n_vcomplete;       /* hcentres_complete / vcentres_complete */
+    int32_t n_stones, n_black, n_white, side_to_move;
+    int32_t pad0;
+    double hspace, vspace;                  /* :437-438 */
+    double hcentres[I2S_MAX_CENTRES], vcentres[I2S_MAX_CENTRES];
+    double hcentres_complete[I2S_MAX_CENTRES], vcentres_complete[I2S_MAX_CENTRES];
+    double brightness[I2S_BOARD_SIZE * I2S_BOARD_SIZE];   /* stone_brightnesses (:508-514) */
+    float hlines[I2S_MAX_LINES], vlines[I2S_MAX_LINES];   /* rho, in find_lines' output order */
+    float circles[I2S_MAX_CIRCLES][3];      /* x, y, r */
+    uint8_t circle_kept[I2S_MAX_CIRCLES];   /* 1 if the circle survives the radius filter */
+    uint8_t detected[I2S_BOARD_SIZE][I2S_BOARD_SIZE];     /* detected_board[hsize][vsize] */
+    uint8_t board[I2S_BOARD_SIZE][I2S_BOARD_SIZE];        /* full_board */
+    uint8_t pad1[2];
+} i2s_result;
+
+int  i2s_abi_version(void);
+void i2s_default_params(i2s_params* p);
+int  i2s_choose_threshold(int w, int h);
+const char* i2s_strerror(int code);
+const char* i2s_last_error(const i2s_ctx* ctx);
+
+/* device_id >= 0. max_batch = images processed per device pass (workspace is sized for it);
+ * detect_batch accepts any B and loops over passes. */
+int  i2s_create(i2s_ctx** out, int device_id, int max_batch, int max_w, int max_h);
+void i2s_destroy(i2s_ctx* ctx);
+
+/* img[b]: row-major, channels interleaved, channels[b] in {1,3}; stride[b] in bytes.
+ * boards: [B] (required). full: [B] or NULL. */
+int  i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img,
+                      const int* w, const int* h, const int* stride, const int* channels,
+                      const i2s_params* p, i2s_board* boards, i2s_result* full);
+
+/* Re-run the stone classifier on the images of the LAST pass of the last detect call
+ * (first..first+n) with p->black_threshold / p->align_*; circles, lines and grid are reused. */
+int  i2s_classify_batch(i2s_ctx* ctx, int first, int n, const i2s_params* p,
+                        i2s_board* boards, i2s_result* full);
+
+/* find_grid() on injected data for ONE image: grey (host, w*h, stride w), circles [n][3],
+ * hlines/vlines rho lists exactly as find_lines returns them. */
+int  i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int h,
+                         const float* circles, int n_circles,
+                         const float* hlines, int n_h, const float* vlines, int n_v,
+                         const i2s_params* p, i2s_board* board, i2s_result* full);
+
+/* Copy one plane of image `index` of the last pass to host memory (dst: h rows of w bytes). */
+int  i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* dst, size_t dst_stride);
+
+/* Stage timing of the last detect call, milliseconds measured with HIP events on the context's
+ * stream: [0] blur+Canny (grey, median, gauss, sobel/NMS, hysteresis of all 9 maps),
+ * [1] Hough circles, [2] erase + Hough lines, [3] grid + classifier, [4] total. */
+int  i2s_last_timing(const i2s_ctx* ctx, float ms[5]);
+
+/* Debug/test hooks (not part of the drop-in surface): Hough-circle accumulator of variant v
+ * ((h)x(w) int32, cell layout = pixel layout) and line accumulators. Enabled by
+ * i2s_set_debug(ctx, 1) before the detect call. */
+int  i2s_set_debug(i2s_ctx* ctx, int on);
+int  i2s_fetch_circle_acc(i2s_ctx* ctx, int index, int variant, int32_t* dst);
+int  i2s_fetch_line_acc(i2s_ctx* ctx, int index, int32_t* dst, size_t cap, int* numrho, int* nangles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2S_H */

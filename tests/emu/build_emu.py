@@ -1,0 +1,28 @@
+"""Builds tests/emu/libi2s_emu.so: the UNMODIFIED product sources (img2sgf_amd/csrc) compiled with g++ against
+the fiber-based HIP emulation in tests/emu/hip/hip_runtime.h.  Test infrastructure only: lets the GPU-less CI
+check kernel logic against the oracle.  The product loader never looks at this file."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "img2sgf_amd", "csrc")
+LIB = os.path.join(HERE, "libi2s_emu.so")
+
+
+def build(force=False):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+        os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+        os.path.join(ROOT, "include", "i2s.h")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+           "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-sign-compare",
+           "-I", HERE, "-x", "c++", os.path.join(CSRC, "i2s_api.hip"), os.path.join(HERE, "hipemu.cpp"),
+           "-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))
