@@ -6,7 +6,7 @@ only, 9 hoshi discs of radius 3, every intersection independently empty / black 
 0.55 / 0.225 / 0.225 from numpy Generator(PCG64(seed)); a black stone is a filled disc of radius 23 centred on
 (x_k+0.5, y_k+0.5), a white stone a white disc with a 2-px black ring (radii 21..23) that hides the grid lines
 under it.  Enters the pipeline where the reference holds `input_image_np` (img2sgf.py:150), C = 1.
-Smaller geometries (same construction) keep the emulated / oracle parity tests fast.
+Smaller geometries (same construction) keep the CPU-side parity tests fast.
 """
 from dataclasses import dataclass
 

@@ -1,0 +1,34 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a 2-process gloo job.  Each rank detects its shard of a small
+synthetic batch (with the emulated build of the product sources, there is no GPU here) and all-gathers the boards."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    import torch.distributed as dist
+    import emu_util
+    from img2sgf_amd import dist as i2s_dist, synth
+    from img2sgf_amd.pipeline import Detector
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    total = int(sys.argv[1])
+    out = sys.argv[2]
+    dist.init_process_group("gloo")
+    lo, hi = i2s_dist.shard_range(total, rank, world)
+    imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(lo, hi)]
+    det = Detector(0, 2, 300, 260, lib=emu_util.emu_library())
+    boards = det.detect_batch(imgs, full=False)
+    allb = i2s_dist.allgather_boards(boards, world)
+    assert allb.shape == (total, 384)
+    np.save(os.path.join(out, "rank%d.npy" % rank), allb)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

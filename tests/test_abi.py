@@ -1,0 +1,55 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/i2s.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from img2sgf_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.I2sLibrary(build.build())
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "i2s.h")).read()
+    declared = set(re.findall(r"\b(i2s_[a-z_0-9]+)\s*\(", hdr)) - {"i2s_ctx"}
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib.dll, name), name
+
+
+def test_struct_sizes_and_defaults(lib):
+    p = _lib.I2sParams()
+    lib.dll.i2s_default_params(C.byref(p))
+    assert (p.canny_lo, p.canny_hi, p.hc_param1, p.hc_param2, p.hc_min_radius, p.hc_max_radius) == (50, 200, 100, 30, 1, 30)
+    assert (p.black_threshold, p.align_x, p.align_y, p.min_grid_spacing, p.big_space_ratio) == (128, 2, 0, 10.0, 1.6)
+    assert lib.dll.i2s_abi_version() == 1
+    assert lib.dll.i2s_choose_threshold(750, 747) == 74 and lib.dll.i2s_choose_threshold(1024, 1024) == 96
+    assert lib.dll.i2s_strerror(-2).decode().startswith("no HIP device")
+
+
+def test_product_has_no_cpu_fallback(lib):
+    """Without a GPU the product must fail loudly, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    rc = lib.dll.i2s_create(C.byref(ctx), 0, 1, 64, 64)
+    assert rc == -2 and not ctx.value
+    from img2sgf_amd.pipeline import Detector, I2sError
+    with pytest.raises(I2sError):
+        Detector(0, 1, 64, 64)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "img2sgf_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|libi2s_oracle|oracle/", txt, re.M), os.path.join(dp, f)

@@ -1,0 +1,109 @@
+"""GPU-less logic tests: the UNMODIFIED product sources (kernels + C ABI) compiled against the fiber-based
+HIP emulation in tests/emu and checked bit for bit against the oracle.  These do not replace the -m gpu parity
+tests; they keep indexing/logic regressions out of the GPU runs."""
+import os
+
+import numpy as np
+import pytest
+
+import emu_util
+import parity
+from helpers import GOLDEN, load_glue_golden, synth_grey
+from img2sgf_amd import synth
+from img2sgf_amd.pipeline import Detector, Params, I2sError
+from oracle import pipeline as opipe
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_util.emu_library()
+
+
+def test_small_synthetic_with_internals(lib):
+    det = Detector(0, 2, 300, 260, lib=lib)
+    imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in (0, 1)]
+    dets = parity.run_and_compare(det, imgs, internals=True)
+    for s, d in zip((0, 1), dets):
+        occ = synth.occupancy(s, 9, 8)
+        assert d.board_ready and (d.full_board[:9, :8] == occ).all()
+    det.close()
+
+
+def test_multi_pass_ragged_batch(lib):
+    """3 images of different sizes through a context holding 2 per device pass."""
+    det = Detector(0, 2, 320, 300, lib=lib)
+    a = synth.synth_diagram(2, geom=synth.GEOM_SMALL)[0]
+    b = np.ascontiguousarray(a[:200, :250])
+    c = np.pad(a, ((10, 30), (5, 40)), constant_values=255)
+    parity.run_and_compare(det, [a, b, c])
+    det.close()
+
+
+@pytest.mark.parametrize("name", ["no_circles.jpg", "ex9.jpg"])
+def test_reference_fixture(lib, name):
+    img = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", name))
+    det = Detector(0, 1, img.shape[1], img.shape[0], lib=lib)
+    parity.run_and_compare(det, [img], internals=True)
+    det.close()
+
+
+def test_tiny_images(lib):
+    det = Detector(0, 4, 70, 70, lib=lib)
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (h, w), dtype=np.uint8) for (h, w) in [(1, 1), (2, 5), (7, 3), (33, 65)]]
+    parity.run_and_compare(det, imgs)
+    det.close()
+
+
+def test_reclassify(lib):
+    """apply_black_thresh (img2sgf.py:762-766): identify_board only, with a new threshold / alignment."""
+    det = Detector(0, 1, 300, 260, lib=lib)
+    img = synth.synth_diagram(3, geom=synth.GEOM_SMALL)[0]
+    det.detect_batch([img])
+    d2 = det.classify(0, 1, Params(black_threshold=250, alignment=(3, 1)))[0]
+    ref = opipe.process_image(img, black_thr=250, alignment=(3, 1))
+    parity.compare_detection(d2, ref)
+    assert d2.num_white_stones == 0
+    det.close()
+
+
+G = load_glue_golden()
+
+
+def test_glue_golden_through_c_abi(lib):
+    """find_grid() on injected rho lists / circles: the device glue against vectors produced by the reference."""
+    det = Detector(0, 1, 1000, 1000, lib=lib)
+    for entry in G["cases"]:
+        case, exp = entry["case"], entry["expect"]
+        grey = synth_grey(case["w"], case["h"], case["seed"])
+        d = det.grid_from_lines(grey, np.array(case["circles"], np.float32).reshape(-1, 3), case["hlines"], case["vlines"],
+                                Params(line_threshold=case["threshold"], black_threshold=case["black_thr"],
+                                       alignment=case["alignment"]))
+        name = case["name"]
+        assert d.found_grid == exp["found_grid"] and d.valid_grid == exp["valid_grid"], name
+        assert d.board_ready == exp["board_ready"], name
+        np.testing.assert_array_equal(d.hcentres, np.array(exp["hcentres"]), err_msg=name)
+        np.testing.assert_array_equal(d.vcentres, np.array(exp["vcentres"]), err_msg=name)
+        assert (d.hsize, d.vsize) == (exp["hsize"], exp["vsize"]), name
+        if exp["valid_grid"]:
+            np.testing.assert_array_equal(d.hcentres_complete, np.array(exp["hcentres_complete"]), err_msg=name)
+            np.testing.assert_array_equal(d.vcentres_complete, np.array(exp["vcentres_complete"]), err_msg=name)
+            assert (d.hspace, d.vspace) == (exp["hspace"], exp["vspace"]), name
+            np.testing.assert_array_equal(d.circles, np.array(exp["kept_circles"], np.float32).reshape(-1, 3), err_msg=name)
+        if exp["board_ready"]:
+            np.testing.assert_array_equal(d.detected_board, np.array(exp["detected_board"]), err_msg=name)
+            np.testing.assert_array_equal(d.full_board, np.array(exp["full_board"]), err_msg=name)
+            np.testing.assert_array_equal(d.stone_brightnesses, np.array(exp["stone_brightnesses"]), err_msg=name)
+            assert (d.num_black_stones, d.num_white_stones, d.side_to_move) == (
+                exp["num_black_stones"], exp["num_white_stones"], exp["side_to_move"]), name
+            assert d.sgf == exp["sgf"], name
+    det.close()
+
+
+def test_errors(lib):
+    det = Detector(0, 1, 64, 64, lib=lib)
+    with pytest.raises(I2sError):
+        det.detect_batch([np.zeros((65, 10), np.uint8)])
+    with pytest.raises(I2sError):
+        det.detect_batch([np.zeros((10, 10), np.uint8)], Params(hc_max_radius=40))
+    det.close()
