@@ -104,7 +104,7 @@ def main():
             "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU, device-resident, full "
                                    "hot path incl. board all-gather" % B, "pass_size": det.max_batch,
                        "boards_match_generator": ok},
-            "roofline": {"bound": "hbm", "kernel": "blur+Canny stage (grey, 3 medians, 3 Gaussians, Sobel/NMS x9, hysteresis)",
+            "roofline": {"bound": "hbm", "kernel": "blur+Canny stage (k_grey, k_median<3,5,7>, k_gauss<3,5,7>, k_sobel_nms_src, k_hysteresis, k_edges_from_map)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES},
             "stage_ms_last_step": timing,

@@ -39,6 +39,8 @@ struct i2s_ctx {
     int* d_counts = nullptr;     // cent_count | est_count | vcount | overflow
     unsigned long long* d_est_keys = nullptr;
     float* d_vcirc = nullptr;
+    uint2* d_bin_ent = nullptr;
+    int* d_bin_cnt = nullptr;
     int* d_lacc = nullptr;
     int lrow = 0;
     i2s_result* d_res = nullptr;
@@ -111,7 +113,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -133,6 +135,8 @@ static int create_impl(i2s_ctx* ctx)
     g.wmax = ctx->max_w;
     g.nb = ctx->max_batch;
     g.slot = (long long)g.pitch * g.hmax;
+    g.bw = (ctx->max_w + EB - 1) / EB;
+    g.bins = g.bw * ((ctx->max_h + EB - 1) / EB);
     const size_t nb = ctx->max_batch;
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
     ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
@@ -145,6 +149,8 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_counts, counts_bytes(ctx)));
     I2S_HIP(hipMalloc(&ctx->d_est_keys, nb * NVAR * EST_CAP * sizeof(unsigned long long)));
     I2S_HIP(hipMalloc(&ctx->d_vcirc, nb * NVAR * VCIRC_CAP * 3 * sizeof(float)));
+    I2S_HIP(hipMalloc(&ctx->d_bin_cnt, nb * NVAR * g.bins * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_bin_ent, nb * NVAR * g.bins * EB_CAP * sizeof(uint2)));
     ctx->lrow = (2 * (ctx->max_w + ctx->max_h) + 1 + 15) / 16 * 16;
     I2S_HIP(hipMalloc(&ctx->d_lacc, nb * LROWS * ctx->lrow * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_res, nb * sizeof(i2s_result)));
@@ -306,17 +312,20 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         rc = run_hysteresis(ctx, 0, 0, 1, g_h);
         if (rc) return rc;
         hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES));
+        I2S_HIP(hipEventRecord(ctx->ev[1], st));
         {
             const dim3 g_v(g_f.x, g_f.y, nb * NVAR);
             hipLaunchKernelGGL(k_sobel_nms_var, g_v, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot, 0, hc_lo, p->hc_param1);
         }
         rc = run_hysteresis(ctx, 1, 1, NVAR, g_h);
         if (rc) return rc;
-        I2S_HIP(hipEventRecord(ctx->ev[1], st));
 
         {
             const dim3 g_vote((wmax + VT - 1) / VT, (hmax + VT - 1) / VT, nb * NVAR);
-            hipLaunchKernelGGL(k_vote_centres, g_vote, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
+            const dim3 g_bins((wmax + EB - 1) / EB, (hmax + EB - 1) / EB, nb * NVAR);
+            hipLaunchKernelGGL(k_edge_bins, g_bins, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
+                               ctx->d_bin_ent, ctx->d_bin_cnt);
+            hipLaunchKernelGGL(k_vote_centres, g_vote, dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                                p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
                                ctx->debug ? ctx->d_dbg_acc : (int*)nullptr);
             hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, map0 + (size_t)nb * g.slot,

@@ -38,6 +38,7 @@ struct Geo {
     int hmax;             // rows per plane slot
     int nb;               // images in this pass
     int wmax;
+    int bw, bins;         // edge bins per row / per plane (32x32-pixel cells)
     long long slot;       // pitch * hmax
 };
 

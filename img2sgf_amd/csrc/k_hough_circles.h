@@ -1,9 +1,11 @@
 // cv.HoughCircles(img, HOUGH_GRADIENT, dp=1, minDist, param1, param2, minRadius, maxRadius) (img2sgf.py:180)
 // after OpenCV hough.cpp HoughCirclesGradient (>= 3.4.2 / 4.x), restructured for CDNA4:
+//   k_edge_bins     : edge pixels -> 8-byte records (position + fixed-point unit gradient) binned by 32x32 cell.
 //   k_vote_centres  : the 2-D accumulator never exists in HBM.  Each workgroup owns a 126x126 block of
-//                     accumulator cells (+1-cell apron) as a 64 KB LDS tile, gathers the edge pixels whose
-//                     gradient rays can reach it (LDS compaction list), casts the votes with LDS atomics and
-//                     tests the 4-neighbour local-maximum rule in place; only centre candidates leave the CU.
+//                     accumulator cells (+1-cell apron) as a 33 KB LDS tile of 16-bit counters, streams the edge
+//                     bins within reach, casts the votes with LDS atomics (one wavefront per edge record, one lane
+//                     per ray step) and tests the 4-neighbour local-maximum rule in place; only centre candidates
+//                     leave the CU.
 //   k_radius        : one wavefront per centre: 10-bins-per-pixel radius histogram of the edge bitmap in LDS.
 //   k_circles_final : per (image, variant) bitonic sort by OpenCV's total order + greedy min-dist pass.
 #pragma once
@@ -13,100 +15,159 @@ namespace i2s {
 
 constexpr int VT = 126;          // accumulator cells per tile side (interior)
 constexpr int VL = VT + 2;       // LDS tile side incl. apron
-constexpr int VSTRIP = 16;       // candidate rows gathered per compaction round
-constexpr int VLIST_CAP = VSTRIP * (VL + 2 * 30);   // worst case: every scanned pixel is an edge
+constexpr int VASTR = 130;       // tile row stride in 16-bit cells: 65 dwords == 1 (mod 32 banks), so vertical rays spread over banks
+constexpr int VTHREADS = 512;
+constexpr int EB = 32;           // edge bins: EB x EB pixel cells
+constexpr int EB_CAP = EB * EB;  // worst case: every pixel of a bin is an edge
 
-// Sobel 3x3 with BORDER_REPLICATE at one pixel of a single-channel plane.
-__device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitch, int w, int h, int x, int y, int& dx, int& dy)
+// ---- edge bins -------------------------------------------------------------------------------------------------------
+// After hysteresis, every edge pixel of a HoughCircles input becomes one 8-byte record
+//   .x = x | y << 16,  .y = (sx & 0xffff) | sy << 16
+// with (sx, sy) = cvRound(d * 1024 / |d|) of its Sobel gradient d (hough.cpp HoughCirclesAccumInvoker), stored in the
+// bin of its 32x32-pixel cell.  The vote kernel then streams only the bins within reach of its accumulator tile.
+// grid (bins_x, bins_y, nb * NVAR), block 256 (4 pixels per thread).
+// bin_cnt[(bv * g.bins) + by * g.bw + bx], bin_ent[... * EB_CAP + k].
+__global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ desc, Geo g,
+                                                   const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
+                                                   uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt)
 {
-    const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
-    const int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
-    const uint8_t* r0 = p + (size_t)ym * pitch;
-    const uint8_t* r1 = p + (size_t)y * pitch;
-    const uint8_t* r2 = p + (size_t)yp * pitch;
-    const int a = r0[xm], b = r0[x], c = r0[xp], d = r1[xm], f = r1[xp], gg = r2[xm], hh = r2[x], ii = r2[xp];
-    dx = (c + 2 * f + ii) - (a + 2 * d + gg);
-    dy = (gg + 2 * hh + ii) - (a + 2 * b + c);
+    __shared__ uint8_t s_p[EB + 2][EB + 4];
+    __shared__ int s_n;
+    const int b = blockIdx.z / NVAR, v = blockIdx.z % NVAR;
+    const int w = desc[b].w, h = desc[b].h;
+    const int x0 = blockIdx.x * EB, y0 = blockIdx.y * EB;
+    if (x0 >= w || y0 >= h) return;
+    const int tid = threadIdx.x;
+    const size_t off = ((size_t)v * g.nb + b) * g.slot;
+    const uint8_t* plane = planes + off;
+    const uint8_t* map = maps + off;
+    const size_t bin = (size_t)(b * NVAR + v) * g.bins + (size_t)blockIdx.y * g.bw + blockIdx.x;
+    if (tid == 0) s_n = 0;
+    for (int i = tid; i < (EB + 2) * (EB + 2); i += 256) {
+        const int ly = i / (EB + 2), lx = i - ly * (EB + 2);
+        const int gy = iclamp(y0 + ly - 1, 0, h - 1), gx = iclamp(x0 + lx - 1, 0, w - 1);   // BORDER_REPLICATE
+        s_p[ly][lx] = plane[(size_t)gy * g.pitch + gx];
+    }
+    __syncthreads();
+    // thread -> 4 consecutive pixels of one row (one aligned dword of the map)
+    const int ly = tid >> 3, lx4 = (tid & 7) * 4;
+    const int y = y0 + ly;
+    uint2* out = bin_ent + bin * EB_CAP;
+    if (y < h && x0 + lx4 < w) {
+        const unsigned m4 = *reinterpret_cast<const unsigned*>(map + (size_t)y * g.pitch + x0 + lx4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int lx = lx4 + q, x = x0 + lx;
+            if (x < w && ((m4 >> (8 * q)) & 0xffu) == 2u) {
+                const int a = s_p[ly][lx], bb = s_p[ly][lx + 1], c = s_p[ly][lx + 2];
+                const int d = s_p[ly + 1][lx], f = s_p[ly + 1][lx + 2];
+                const int gg = s_p[ly + 2][lx], hh = s_p[ly + 2][lx + 1], ii = s_p[ly + 2][lx + 2];
+                const int dx = (c + 2 * f + ii) - (a + 2 * d + gg);
+                const int dy = (gg + 2 * hh + ii) - (a + 2 * bb + c);
+                if (dx == 0 && dy == 0) continue;
+                const float vx = (float)dx, vy = (float)dy;
+                const float mag = sqrtf(vx * vx + vy * vy);
+                if (mag < 1.0f) continue;
+                const int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
+                const int sy = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
+                const int k = atomicAdd(&s_n, 1);
+                out[k] = make_uint2((unsigned)x | ((unsigned)y << 16), ((unsigned)sx & 0xffffu) | ((unsigned)sy << 16));
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) bin_cnt[bin] = s_n;
 }
 
-// grid (tiles_x, tiles_y, nb * NVAR).  planes/maps: variant v of image b at (v * nb + b) * slot (maps = map 1 base).
+// grid (tiles_x, tiles_y, nb * NVAR), block 512.
 // cent_list[(b * NVAR + v) * CENT_CAP + i] = x | y << 16 of an accumulator local maximum; cent_count likewise.
 // dbg_acc (optional): dense int32 accumulator, cell (x,y) of (b,v) at ((b * NVAR + v) * hmax + y) * pitch + x.
-__global__ __launch_bounds__(256) void k_vote_centres(const ImgDesc* __restrict__ desc, Geo g,
-                                                      const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
+//
+// Votes of one edge pixel: cells ((x*1024 +- r*sx) >> 10, (y*1024 +- r*sy) >> 10), r = min_r..max_r, that lie inside the
+// image (OpenCV walks r upward and breaks at the first cell outside; the walk is a straight line from inside a convex
+// image, so "break" == "skip every outside cell").  The (edge, direction, r) items are independent: one wavefront
+// takes one edge record per round, lane = direction * nsteps + step.  The 2-D accumulator never exists in HBM: each
+// workgroup owns 126x126 cells (+1-cell apron) in LDS and tests the 4-neighbour local-maximum rule in place.
+// Cell counts are 16-bit halves of LDS dwords: a cell receives at most 3 votes from each of the < 3100 edge pixels
+// within max_r <= 30 of it, so a half never carries into its neighbour.
+__global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict__ desc, Geo g,
+                                                      const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
                                                       int min_r, int max_r, int acc_thr,
                                                       unsigned* __restrict__ cent_list, int* __restrict__ cent_count,
                                                       int* __restrict__ dbg_acc)
 {
-    __shared__ unsigned s_acc[VL * VL];
-    __shared__ unsigned s_list[VLIST_CAP];
-    __shared__ int s_n;
+    __shared__ unsigned s_acc[VL * VASTR / 2];
     const int b = blockIdx.z / NVAR, v = blockIdx.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
     const int cx0 = blockIdx.x * VT, cy0 = blockIdx.y * VT;    // first interior cell
     if (cx0 >= w || cy0 >= h) return;
     const int tid = threadIdx.x;
-    const size_t off = ((size_t)v * g.nb + b) * g.slot;
-    const uint8_t* plane = planes + off;
-    const uint8_t* map = maps + off;
-    for (int i = tid; i < VL * VL; i += 256) s_acc[i] = 0;
-    // LDS tile covers cells [lx0, lx0 + VL) x [ly0, ly0 + VL)
+    const int bv = b * NVAR + v;
+    for (int i = tid; i < VL * VASTR / 2; i += VTHREADS) s_acc[i] = 0;
+    __syncthreads();
+    // LDS tile covers cells [lx0, lx0 + VL) x [ly0, ly0 + VL); edge pixels within max_r of it can vote into it
     const int lx0 = cx0 - 1, ly0 = cy0 - 1;
-    // edge pixels that can vote into the tile: within max_r of it (|step| <= 1024 per radius unit)
-    const int rx0 = imax(lx0 - max_r, 0), rx1 = imin(lx0 + VL + max_r, w);
-    const int ry0 = imax(ly0 - max_r, 0), ry1 = imin(ly0 + VL + max_r, h);
-    const int cw = rx1 - rx0;
-    for (int sy = ry0; sy < ry1; sy += VSTRIP) {
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        const int rows = imin(VSTRIP, ry1 - sy);
-        for (int i = tid; i < rows * cw; i += 256) {
-            const int ly = i / cw, lx = i - ly * cw;
-            const int x = rx0 + lx, y = sy + ly;
-            if (map[(size_t)y * g.pitch + x] == 2) {
-                const int k = atomicAdd(&s_n, 1);
-                s_list[k] = (unsigned)x | ((unsigned)y << 16);
+    const int bx0 = imax(lx0 - max_r, 0) / EB, bx1 = imin(lx0 + VL - 1 + max_r, w - 1) / EB;
+    const int by0 = imax(ly0 - max_r, 0) / EB, by1 = imin(ly0 + VL - 1 + max_r, h - 1) / EB;
+    const int nbx = bx1 - bx0 + 1, nbin = nbx * (by1 - by0 + 1);
+    // cells of this tile that exist in the image: one unsigned compare per axis covers "inside image" and "inside tile"
+    const int vx_lo = imax(lx0, 0), vy_lo = imax(ly0, 0);
+    const unsigned vx_n = (unsigned)(imin(lx0 + VL, w) - vx_lo), vy_n = (unsigned)(imin(ly0 + VL, h) - vy_lo);
+    const int nsteps = max_r - min_r + 1;          // <= 31
+    const int lane = tid & 63, wave = tid >> 6;
+    const int dir = lane >= nsteps ? 1 : 0;
+    const int st = lane - dir * nsteps;
+    const bool act = st < nsteps;                  // lanes 2 * nsteps .. 63 idle
+    const int r = dir ? -(min_r + st) : (min_r + st);
+    const size_t bin_base = (size_t)bv * g.bins;
+    // one wavefront per bin: a coalesced 512-byte load brings 64 edge records, every lane tests whether ITS record's
+    // ray segment (+-max_r steps) can touch the tile at all, then the wave walks the surviving records one by one.
+    for (int q = wave; q < nbin; q += VTHREADS / 64) {
+        const int by = by0 + q / nbx, bx = bx0 + q % nbx;
+        const size_t bin = bin_base + (size_t)by * g.bw + bx;
+        const int n = bin_cnt[bin];
+        const uint2* ent = bin_ent + bin * EB_CAP;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            uint2 mine = make_uint2(0u, 0u);
+            bool reach = false;
+            if (k0 + lane < n) {
+                mine = ent[k0 + lane];
+                const int ex = (int)(mine.x & 0xffffu), ey = (int)(mine.x >> 16);
+                const int sx = (int)(short)(mine.y & 0xffffu), sy = (int)(short)(mine.y >> 16);
+                // the 2 * nsteps vote cells lie within +-(max_r * |s| >> 10) + 1 of the pixel on each axis
+                const int ddx = ((max_r * iabs_(sx)) >> 10) + 1, ddy = ((max_r * iabs_(sy)) >> 10) + 1;
+                reach = ex + ddx >= vx_lo && ex - ddx < vx_lo + (int)vx_n && ey + ddy >= vy_lo && ey - ddy < vy_lo + (int)vy_n;
             }
-        }
-        __syncthreads();
-        const int n = s_n;
-        for (int k = tid; k < n; k += 256) {
-            const unsigned e = s_list[k];
-            const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
-            int dx, dy;
-            sobel_at(plane, g.pitch, w, h, x, y, dx, dy);
-            if (dx == 0 && dy == 0) continue;
-            const float vx = (float)dx, vy = (float)dy;
-            const float mag = sqrtf(vx * vx + vy * vy);
-            if (mag < 1.0f) continue;
-            int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
-            int sy2 = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
-            const int xb = x * 1024, yb = y * 1024;
-            for (int k1 = 0; k1 < 2; k1++) {
-                int x1 = xb + min_r * sx, y1 = yb + min_r * sy2;
-                for (int r = min_r; r <= max_r; x1 += sx, y1 += sy2, r++) {
-                    const int x2 = x1 >> 10, y2 = y1 >> 10;
-                    if ((unsigned)x2 >= (unsigned)w || (unsigned)y2 >= (unsigned)h) break;
-                    const unsigned tx = (unsigned)(x2 - lx0), ty = (unsigned)(y2 - ly0);
-                    if (tx < (unsigned)VL && ty < (unsigned)VL) atomicAdd(&s_acc[ty * VL + tx], 1u);
+            unsigned long long m = __ballot(reach);
+            while (m) {
+                const int j = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const unsigned exy = __shfl(mine.x, j), es = __shfl(mine.y, j);
+                if (!act) continue;
+                const int sx = (int)(short)(es & 0xffffu), sy = (int)(short)(es >> 16);
+                const int x2 = ((int)(exy & 0xffffu) * 1024 + r * sx) >> 10;
+                const int y2 = ((int)(exy >> 16) * 1024 + r * sy) >> 10;
+                const unsigned tx = (unsigned)(x2 - vx_lo), ty = (unsigned)(y2 - vy_lo);
+                if (tx < vx_n && ty < vy_n) {
+                    const unsigned idx = (unsigned)(y2 - ly0) * VASTR + (unsigned)(x2 - lx0);
+                    atomicAdd(&s_acc[idx >> 1], 1u << ((idx & 1u) * 16));
                 }
-                sx = -sx; sy2 = -sy2;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     // centre candidates: cells (x,y), 1 <= x <= w-1, 1 <= y <= h-1 (OpenCV scans padded rows 1..H, cols 1..W
     // of an accumulator whose votes sit at unpadded indices; cells x == W or y == H hold no votes).
-    const int bv = b * NVAR + v;
-    for (int i = tid; i < VT * VT; i += 256) {
+    const unsigned short* acc16 = reinterpret_cast<const unsigned short*>(s_acc);
+    for (int i = tid; i < VT * VT; i += VTHREADS) {
         const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
         const int x = lx0 + tx, y = ly0 + ty;
         if (x >= w || y >= h) continue;
-        const unsigned a = s_acc[ty * VL + tx];
-        if (dbg_acc) dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = (int)a;
+        const int a = acc16[ty * VASTR + tx];
+        if (dbg_acc) dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = a;
         if (x < 1 || y < 1) continue;
-        if ((int)a > acc_thr && a > s_acc[ty * VL + tx - 1] && a >= s_acc[ty * VL + tx + 1] &&
-            a > s_acc[(ty - 1) * VL + tx] && a >= s_acc[(ty + 1) * VL + tx]) {
+        if (a > acc_thr && a > (int)acc16[ty * VASTR + tx - 1] && a >= (int)acc16[ty * VASTR + tx + 1] &&
+            a > (int)acc16[(ty - 1) * VASTR + tx] && a >= (int)acc16[(ty + 1) * VASTR + tx]) {
             const int k = atomicAdd(&cent_count[bv], 1);
             if (k < CENT_CAP) cent_list[(size_t)bv * CENT_CAP + k] = (unsigned)x | ((unsigned)y << 16);
         }

@@ -183,8 +183,9 @@ int  i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int h,
 int  i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* dst, size_t dst_stride);
 
 /* Stage timing of the last detect call, milliseconds measured with HIP events on the context's
- * stream: [0] blur+Canny (grey, median, gauss, sobel/NMS, hysteresis of all 9 maps),
- * [1] Hough circles, [2] erase + Hough lines, [3] grid + classifier, [4] total. */
+ * stream: [0] blur+Canny (grey, 3 medians, 3 Gaussians, main Canny incl. hysteresis),
+ * [1] Hough circles x8 (their Sobel/Canny, votes, centres, radii, min-dist), [2] erase + Hough lines,
+ * [3] grid + classifier, [4] total. */
 int  i2s_last_timing(const i2s_ctx* ctx, float ms[5]);
 
 /* Debug/test hooks (not part of the drop-in surface): Hough-circle accumulator of variant v
