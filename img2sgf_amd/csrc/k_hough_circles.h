@@ -182,72 +182,104 @@ __device__ __forceinline__ unsigned long long est_key(int acc, int s, int x, int
            ((unsigned long long)(unsigned)x << 16) | (unsigned long long)(unsigned)y;
 }
 
-constexpr int RAD_BINS_MAX = 320;
+constexpr int RAD_BINS_MAX = 320;   // 5 x 64
 
+// Radius estimate + support check of every centre candidate (hough.cpp HoughCircleEstimateRadiusInvoker).
 // grid (RAD_GX, nb * NVAR), block 256 = 4 wavefronts, one centre per wavefront per round.
+// The voting edge pixels near the centre come from the edge bins (the same set OpenCV keeps in `nz`); their distances
+// go into a 10-bins-per-pixel LDS histogram; the histogram scan (windows of 10 bins opened at every non-empty bin,
+// walking down from the largest radius) runs wave-uniformly on prefix sums + 64-bit occupancy masks.
 // est_keys[(b*NVAR+v) * EST_CAP + i], est_count[b*NVAR+v].
-__global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ maps,
+__global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc, Geo g,
+                                                const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
                                                 const unsigned* __restrict__ cent_list, const int* __restrict__ cent_count,
                                                 int min_r, int max_r, int acc_thr,
                                                 unsigned long long* __restrict__ est_keys, int* __restrict__ est_count)
 {
     __shared__ int s_bins[4][RAD_BINS_MAX];
     const int bv = blockIdx.y;
-    const int b = bv / NVAR, v = bv % NVAR;
+    const int b = bv / NVAR;
     const int w = desc[b].w, h = desc[b].h;
     const int n = imin(cent_count[bv], CENT_CAP);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint8_t* map = maps + ((size_t)v * g.nb + b) * g.slot;
     const int nBinsPerDr = 10;
     int nBins = __float2int_rn((float)(max_r - min_r) / 1.0f * (float)nBinsPerDr);
     if (nBins < 1) nBins = 1;
     const float minR2 = (float)min_r * (float)min_r, maxR2 = (float)max_r * (float)max_r;
+    const size_t bin_base = (size_t)bv * g.bins;
+    int* bins = s_bins[wave];
     for (int c0 = blockIdx.x * 4; c0 < n; c0 += gridDim.x * 4) {
         const int c = c0 + wave;
         const bool live = c < n;
-        for (int i = lane; i < nBins; i += 64) s_bins[wave][i] = 0;
+        for (int i = lane; i < RAD_BINS_MAX; i += 64) bins[i] = 0;
         __syncthreads();
         int cxi = 0, cyi = 0;
         if (live) {
             const unsigned e = cent_list[(size_t)bv * CENT_CAP + c];
             cxi = (int)(e & 0xffffu); cyi = (int)(e >> 16);
             const float cx = ((float)cxi + 0.5f) * 1.0f, cy = ((float)cyi + 0.5f) * 1.0f;
-            // NZPointSet::filterCircles box: [int(c - (maxR+1)), int(c + (maxR+1))) clipped to the image
-            const int rOuter = max_r + 1;
-            const int bx0 = imax((int)(cx - (float)rOuter), 0), bx1 = imin((int)(cx + (float)rOuter), w);
-            const int by0 = imax((int)(cy - (float)rOuter), 0), by1 = imin((int)(cy + (float)rOuter), h);
-            const int bw = bx1 - bx0, npx = bw * (by1 - by0);
-            for (int i = lane; i < npx; i += 64) {
-                const int yy = i / bw, xx = i - yy * bw;
-                const int px = bx0 + xx, py = by0 + yy;
-                if (map[(size_t)py * g.pitch + px] != 2) continue;
-                const float ddx = cx - (float)px, ddy = cy - (float)py;
-                const float r2 = ddx * ddx + ddy * ddy;
-                if (minR2 <= r2 && r2 <= maxR2) {
-                    const float d = sqrtf(r2);
-                    int bin = __float2int_rn((d - (float)min_r) / 1.0f * (float)nBinsPerDr);
-                    bin = imax(0, imin(nBins - 1, bin));
-                    atomicAdd(&s_bins[wave][bin], 1);
-                }
-            }
-        }
-        __syncthreads();
-        if (live && lane == 0) {
-            const int* bins = s_bins[wave];
-            int maxCount = 0, sBest = 0;
-            float rBest = 0.f;
-            for (int j = nBins - 1; j > 0; j--) {
-                if (bins[j]) {
-                    const int upbin = j;
-                    int curCount = 0;
-                    for (; j > upbin - nBinsPerDr && j >= 0; j--) curCount += bins[j];
-                    const float rCur = (float)(upbin + j) / 2.f / (float)nBinsPerDr * 1.0f + (float)min_r;
-                    if (((float)curCount * rBest >= (float)maxCount * rCur) || (rBest < 1.1920929e-07f && curCount >= maxCount)) {
-                        rBest = rCur; maxCount = curCount; sBest = upbin + j;
+            // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: bins overlapping that box
+            const int bx0 = imax(cxi - max_r, 0) / EB, bx1 = imin(cxi + max_r + 1, w - 1) / EB;
+            const int by0 = imax(cyi - max_r, 0) / EB, by1 = imin(cyi + max_r + 1, h - 1) / EB;
+            for (int by = by0; by <= by1; by++)
+                for (int bx = bx0; bx <= bx1; bx++) {
+                    const size_t bin = bin_base + (size_t)by * g.bw + bx;
+                    const int cnt = bin_cnt[bin];
+                    const uint2* ent = bin_ent + bin * EB_CAP;
+                    for (int k = lane; k < cnt; k += 64) {
+                        const unsigned xy = ent[k].x;
+                        const float ddx = cx - (float)(int)(xy & 0xffffu), ddy = cy - (float)(int)(xy >> 16);
+                        const float r2 = ddx * ddx + ddy * ddy;
+                        if (minR2 <= r2 && r2 <= maxR2) {
+                            const float d = sqrtf(r2);
+                            int bi = __float2int_rn((d - (float)min_r) / 1.0f * (float)nBinsPerDr);
+                            bi = imax(0, imin(nBins - 1, bi));
+                            atomicAdd(&bins[bi], 1);
+                        }
                     }
                 }
+        }
+        __syncthreads();
+        // inclusive prefix sums P[i] (in place) and occupancy masks, 64 bins per step
+        unsigned long long occ[RAD_BINS_MAX / 64];
+        int carry = 0;
+#pragma unroll
+        for (int q = 0; q < RAD_BINS_MAX / 64; q++) {
+            const int vraw = bins[q * 64 + lane];
+            occ[q] = __ballot(vraw != 0);
+            int vsum = vraw;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl(vsum, lane >= d ? lane - d : lane);
+                if (lane >= d) vsum += t;
             }
-            if (maxCount > acc_thr) {
+            vsum += carry;
+            carry = __shfl(vsum, 63);
+            bins[q * 64 + lane] = vsum;
+        }
+        __syncthreads();
+        if (live) {
+            int maxCount = 0, sBest = 0;
+            float rBest = 0.f;
+            int j = nBins - 1;
+            while (j > 0) {
+                // highest non-empty bin u with 1 <= u <= j
+                int u = -1;
+                for (int q = j >> 6; q >= 0; q--) {
+                    unsigned long long mq = occ[q];
+                    if (q == (j >> 6)) { const int top = j & 63; if (top < 63) mq &= (2ull << top) - 1ull; }
+                    if (mq) { u = q * 64 + 63 - __clzll((long long)mq); break; }
+                }
+                if (u < 1) break;
+                const int lo = imax(u - nBinsPerDr, -1);          // j after OpenCV's inner summing loop
+                const int curCount = bins[u] - (lo >= 0 ? bins[lo] : 0);
+                const float rCur = (float)(u + lo) / 2.f / (float)nBinsPerDr * 1.0f + (float)min_r;
+                if (((float)curCount * rBest >= (float)maxCount * rCur) || (rBest < 1.1920929e-07f && curCount >= maxCount)) {
+                    rBest = rCur; maxCount = curCount; sBest = u + lo;
+                }
+                j = lo - 1;                                        // the outer loop's own j--
+            }
+            if (lane == 0 && maxCount > acc_thr) {
                 const int k = atomicAdd(&est_count[bv], 1);
                 if (k < EST_CAP) est_keys[(size_t)bv * EST_CAP + k] = est_key(imin(maxCount, 4095), sBest, cxi, cyi);
             }
