@@ -307,7 +307,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5);
         hipLaunchKernelGGL((k_median<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN7));
         hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7);
-        if (has_c1) hipLaunchKernelGGL((k_sobel_nms_src<1>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi);
+        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, g_f, b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1);
         if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi);
         rc = run_hysteresis(ctx, 0, 0, 1, g_h);
         if (rc) return rc;
@@ -315,7 +315,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
         {
             const dim3 g_v(g_f.x, g_f.y, nb * NVAR);
-            hipLaunchKernelGGL(k_sobel_nms_var, g_v, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot, 0, hc_lo, p->hc_param1);
+            hipLaunchKernelGGL(k_sobel_nms_planes, g_v, b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo, p->hc_param1, 0);
         }
         rc = run_hysteresis(ctx, 1, 1, NVAR, g_h);
         if (rc) return rc;

@@ -4,6 +4,7 @@
 // thresholds, 8-connected hysteresis.  Map values: 0 = weak candidate, 1 = no edge, 2 = edge.
 #pragma once
 #include "i2s_types.h"
+#include "tile_io.h"
 
 namespace i2s {
 
@@ -92,15 +93,106 @@ __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict
     sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, g.pitch);
 }
 
-// HoughCircles' internal Canny for variants [v_first, v_first + gridDim.z / nb): grid.z = nb * nvariants.
-// planes = variant planes base (variant v of image b at (v * nb + b) * slot), maps likewise for map 1+v.
-__global__ __launch_bounds__(256) void k_sobel_nms_var(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
-                                                       uint8_t* __restrict__ maps, int v_first, int low, int high)
+// Sobel + NMS on single-channel PLANES, 4 pixels per thread with dword LDS traffic.
+//   main_mode == 0: HoughCircles' internal Canny of variants [v_first, v_first + gridDim.z / nb): plane v -> map 1 + v.
+//   main_mode == 1: the main Canny (img2sgf.py:162) of greyscale sources: plane 0 (grey == source) -> map 0
+//                   (colour sources go through k_sobel_nms_src<3>).
+// grid (tiles_x, tiles_y, nb * nvariants), block 256, tile 64 x 32 outputs.
+// planes = variant plane 0 base, maps = map 0 base.
+__global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
+                                                          uint8_t* __restrict__ maps, int v_first, int low, int high, int main_mode)
 {
+    constexpr int SROWS = CT_H + 4, SWORDS = CT_W / 4 + 4, SSTR = SWORDS + 1;   // source rows y0-2.., x0-8 .. x0+72
+    constexpr int MROWS = CT_H + 2, MSTRIPS = CT_W / 4 + 2, MSTR = 2 * MSTRIPS + 1;   // mag rows y0-1.., x0-4 .. x0+68 (u16 pairs)
+    __shared__ unsigned s_src[SROWS * SSTR];
+    __shared__ unsigned s_mag[MROWS * MSTR];
     const int b = blockIdx.z % g.nb;
-    const int v = v_first + blockIdx.z / g.nb;
-    const size_t off = ((size_t)v * g.nb + b) * g.slot;
-    sobel_nms_tile<1>(planes + off, g.pitch, desc[b].w, desc[b].h, low, high, maps + off, g.pitch);
+    const int v = main_mode ? 0 : v_first + blockIdx.z / g.nb;
+    if (main_mode && desc[b].cn != 1) return;
+    const int w = desc[b].w, h = desc[b].h;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    if (x0 >= w || y0 >= h) return;
+    const int tid = threadIdx.x;
+    const uint8_t* plane = planes + ((size_t)v * g.nb + b) * g.slot;
+    uint8_t* mp = maps + ((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.slot;
+    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, plane, g.pitch, w, h, x0 - 8, y0 - 2, tid);
+    __syncthreads();
+    // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry
+    constexpr int NSTRIPS = MROWS * MSTRIPS;          // 34 * 18 = 612
+    constexpr int PER = (NSTRIPS + 255) / 256;        // 3
+    short gdx[PER][4], gdy[PER][4];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = tid + k * 256;
+        if (i < NSTRIPS) {
+            const int ry = i / MSTRIPS, s = i - ry * MSTRIPS;
+            int r0[6], r1[6], r2[6];
+            const unsigned* p0 = s_src + ry * SSTR + s;
+            unpack6(p0[0], p0[1], p0[2], r0);
+            unpack6(p0[SSTR], p0[SSTR + 1], p0[SSTR + 2], r1);
+            unpack6(p0[2 * SSTR], p0[2 * SSTR + 1], p0[2 * SSTR + 2], r2);
+            int col[6], dif[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { col[j] = r0[j] + 2 * r1[j] + r2[j]; dif[j] = r2[j] - r0[j]; }
+            const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
+            unsigned m[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int dx = col[q + 2] - col[q], dy = dif[q] + 2 * dif[q + 1] + dif[q + 2];
+                const int gx = gx0 + q;
+                if (gx < 0 || gx >= w || gy < 0 || gy >= h) { dx = 0; dy = 0; }
+                gdx[k][q] = (short)dx; gdy[k][q] = (short)dy;
+                m[q] = (unsigned)(iabs_(dx) + iabs_(dy));
+            }
+            s_mag[ry * MSTR + 2 * s] = m[0] | (m[1] << 16);
+            s_mag[ry * MSTR + 2 * s + 1] = m[2] | (m[3] << 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = tid + k * 256;
+        if (i >= NSTRIPS) continue;
+        const int ry = i / MSTRIPS, s = i - ry * MSTRIPS;
+        if (ry < 1 || ry > CT_H || s < 1 || s > CT_W / 4) continue;      // apron strips only feed neighbours
+        const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
+        if (gy >= h || gx0 >= w) continue;
+        // magnitudes of rows ry-1, ry, ry+1 at columns -1 .. 4 of the strip
+        int mg[3][6];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            const unsigned* pm = s_mag + (ry - 1 + rr) * MSTR + 2 * s;
+            const unsigned a = pm[-1], b0 = pm[0], b1 = pm[1], c = pm[2];
+            mg[rr][0] = (int)(a >> 16); mg[rr][1] = (int)(b0 & 0xffffu); mg[rr][2] = (int)(b0 >> 16);
+            mg[rr][3] = (int)(b1 & 0xffffu); mg[rr][4] = (int)(b1 >> 16); mg[rr][5] = (int)(c & 0xffffu);
+        }
+        unsigned outw = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int mcur = mg[1][q + 1];
+            unsigned o = 1;
+            if (mcur > low) {
+                const int xs = gdx[k][q], ys = gdy[k][q];
+                const int ax = iabs_(xs), ay = iabs_(ys) << 15;
+                const int tg22x = ax * 13573;
+                bool keep;
+                if (ay < tg22x) keep = mcur > mg[1][q] && mcur >= mg[1][q + 2];
+                else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) keep = mcur > mg[0][q + 1] && mcur >= mg[2][q + 1];
+                    else {
+                        const bool neg = (xs ^ ys) < 0;       // s = neg ? -1 : 1 -> compare (row-1, x-s) and (row+1, x+s)
+                        keep = neg ? (mcur > mg[0][q + 2] && mcur > mg[2][q]) : (mcur > mg[0][q] && mcur > mg[2][q + 2]);
+                    }
+                }
+                if (keep) o = (mcur > high) ? 2u : 0u;
+            }
+            outw |= o << (8 * q);
+        }
+        uint8_t* dstp = mp + (size_t)gy * g.pitch + gx0;
+        if (gx0 + 3 < w) *reinterpret_cast<unsigned*>(dstp) = outw;
+        else for (int q = 0; q < 4 && gx0 + q < w; q++) dstp[q] = (uint8_t)(outw >> (8 * q));
+    }
 }
 
 // One hysteresis pass over maps [m_first, m_first + gridDim.z / nb).  Each block iterates its 64x64 tile

@@ -20,6 +20,19 @@ constexpr int VTHREADS = 512;
 constexpr int EB = 32;           // edge bins: EB x EB pixel cells
 constexpr int EB_CAP = EB * EB;  // worst case: every pixel of a bin is an edge
 
+// Sobel 3x3 with BORDER_REPLICATE at one pixel of a single-channel plane.
+__device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitch, int w, int h, int x, int y, int& dx, int& dy)
+{
+    const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+    const int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
+    const uint8_t* r0 = p + (size_t)ym * pitch;
+    const uint8_t* r1 = p + (size_t)y * pitch;
+    const uint8_t* r2 = p + (size_t)yp * pitch;
+    const int a = r0[xm], b = r0[x], c = r0[xp], d = r1[xm], f = r1[xp], gg = r2[xm], hh = r2[x], ii = r2[xp];
+    dx = (c + 2 * f + ii) - (a + 2 * d + gg);
+    dy = (gg + 2 * hh + ii) - (a + 2 * b + c);
+}
+
 // ---- edge bins -------------------------------------------------------------------------------------------------------
 // After hysteresis, every edge pixel of a HoughCircles input becomes one 8-byte record
 //   .x = x | y << 16,  .y = (sx & 0xffff) | sy << 16
@@ -31,7 +44,6 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
                                                    const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
                                                    uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt)
 {
-    __shared__ uint8_t s_p[EB + 2][EB + 4];
     __shared__ int s_n;
     const int b = blockIdx.z / NVAR, v = blockIdx.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
@@ -43,35 +55,31 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     const uint8_t* map = maps + off;
     const size_t bin = (size_t)(b * NVAR + v) * g.bins + (size_t)blockIdx.y * g.bw + blockIdx.x;
     if (tid == 0) s_n = 0;
-    for (int i = tid; i < (EB + 2) * (EB + 2); i += 256) {
-        const int ly = i / (EB + 2), lx = i - ly * (EB + 2);
-        const int gy = iclamp(y0 + ly - 1, 0, h - 1), gx = iclamp(x0 + lx - 1, 0, w - 1);   // BORDER_REPLICATE
-        s_p[ly][lx] = plane[(size_t)gy * g.pitch + gx];
-    }
     __syncthreads();
-    // thread -> 4 consecutive pixels of one row (one aligned dword of the map)
+    // thread -> 4 consecutive pixels of one row (one aligned dword of the map); edges are sparse (a few %), so the
+    // 3x3 neighbourhood of an edge pixel is fetched straight from the plane (L2) instead of staging the whole tile
     const int ly = tid >> 3, lx4 = (tid & 7) * 4;
     const int y = y0 + ly;
     uint2* out = bin_ent + bin * EB_CAP;
     if (y < h && x0 + lx4 < w) {
         const unsigned m4 = *reinterpret_cast<const unsigned*>(map + (size_t)y * g.pitch + x0 + lx4);
+        const unsigned t = m4 ^ 0x02020202u;
+        if (((t - 0x01010101u) & ~t & 0x80808080u) != 0) {      // some byte == 2
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int lx = lx4 + q, x = x0 + lx;
-            if (x < w && ((m4 >> (8 * q)) & 0xffu) == 2u) {
-                const int a = s_p[ly][lx], bb = s_p[ly][lx + 1], c = s_p[ly][lx + 2];
-                const int d = s_p[ly + 1][lx], f = s_p[ly + 1][lx + 2];
-                const int gg = s_p[ly + 2][lx], hh = s_p[ly + 2][lx + 1], ii = s_p[ly + 2][lx + 2];
-                const int dx = (c + 2 * f + ii) - (a + 2 * d + gg);
-                const int dy = (gg + 2 * hh + ii) - (a + 2 * bb + c);
-                if (dx == 0 && dy == 0) continue;
-                const float vx = (float)dx, vy = (float)dy;
-                const float mag = sqrtf(vx * vx + vy * vy);
-                if (mag < 1.0f) continue;
-                const int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
-                const int sy = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
-                const int k = atomicAdd(&s_n, 1);
-                out[k] = make_uint2((unsigned)x | ((unsigned)y << 16), ((unsigned)sx & 0xffffu) | ((unsigned)sy << 16));
+            for (int q = 0; q < 4; q++) {
+                const int x = x0 + lx4 + q;
+                if (x < w && ((m4 >> (8 * q)) & 0xffu) == 2u) {
+                    int dx, dy;
+                    sobel_at(plane, g.pitch, w, h, x, y, dx, dy);
+                    if (dx == 0 && dy == 0) continue;
+                    const float vx = (float)dx, vy = (float)dy;
+                    const float mag = sqrtf(vx * vx + vy * vy);
+                    if (mag < 1.0f) continue;
+                    const int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
+                    const int sy = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
+                    const int k = atomicAdd(&s_n, 1);
+                    out[k] = make_uint2((unsigned)x | ((unsigned)y << 16), ((unsigned)sx & 0xffffu) | ((unsigned)sy << 16));
+                }
             }
         }
     }
