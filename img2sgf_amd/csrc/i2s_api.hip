@@ -39,6 +39,8 @@ struct i2s_ctx {
     int* d_counts = nullptr;     // cent_count | est_count | vcount | overflow
     unsigned long long* d_est_keys = nullptr;
     float* d_vcirc = nullptr;
+    int* d_weak = nullptr;       // [NMAP][nb][tiles] tile holds weak pixels
+    int* d_chg = nullptr;        // [NMAP][nb][tiles] last hysteresis pass (+1) that changed the tile
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
     int* d_lacc = nullptr;
@@ -48,7 +50,7 @@ struct i2s_ctx {
     i2s_board* h_boards = nullptr;
     int* d_dbg_acc = nullptr;
     int debug = 0;
-    int hyst_passes = 12;
+    int hyst_passes = 6;
     int last_nb = 0;
     HoughTrig last_trig{};
     float timing[5] = {0, 0, 0, 0, 0};
@@ -113,7 +115,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -137,7 +139,11 @@ static int create_impl(i2s_ctx* ctx)
     g.slot = (long long)g.pitch * g.hmax;
     g.bw = (ctx->max_w + EB - 1) / EB;
     g.bins = g.bw * ((ctx->max_h + EB - 1) / EB);
+    g.tw = (ctx->max_w + CT_W - 1) / CT_W;
+    g.tiles = g.tw * ((ctx->max_h + CT_H - 1) / CT_H);
     const size_t nb = ctx->max_batch;
+    I2S_HIP(hipMalloc(&ctx->d_weak, nb * NMAP * g.tiles * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_chg, nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
     ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
     I2S_HIP(hipMalloc(&ctx->d_src, nb * ctx->src_slot + 256));
@@ -264,7 +270,7 @@ static int run_hysteresis(i2s_ctx* ctx, int phase, int m_first, int nmaps, dim3 
     dim3 grid(tiles.x, tiles.y, ctx->geo.nb * nmaps);
     for (int pass = 0; pass < ctx->hyst_passes; pass++)
         hipLaunchKernelGGL(k_hysteresis, grid, dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, plane_ptr(ctx, I2S_PLANE_CANNY_MAP),
-                           m_first, flags, pass);
+                           m_first, flags, pass, ctx->d_weak, ctx->d_chg);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], flags + ctx->hyst_passes - 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
@@ -291,38 +297,42 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
         I2S_HIP(hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx), st));
         I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, 2 * HYST_MAX_PASSES * sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(ctx->d_chg, 0, (size_t)ctx->max_batch * NMAP * g.tiles * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
         uint8_t* map0 = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
         const dim3 b64x4(64, 4), b256(256);
         const dim3 g_row((wmax + 255) / 256, (hmax + 3) / 4, nb);
         const dim3 g_f((wmax + FT_W - 1) / FT_W, (hmax + FT_H - 1) / FT_H, nb);
-        const dim3 g_h((wmax + HT - 1) / HT, (hmax + HT - 1) / HT, 1);
+        const dim3 g_h(g_f.x, g_f.y, 1);
 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
         hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift);
-        hipLaunchKernelGGL((k_median<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3));
+        hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3));
+        {
+            const dim3 g_m((wmax + MT_W - 1) / MT_W, (hmax + MT_H - 1) / MT_H, nb);
+            hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+                               plane_ptr(ctx, I2S_PLANE_MEDIAN7));
+        }
         hipLaunchKernelGGL((k_gauss<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3), t3);
-        hipLaunchKernelGGL((k_median<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5));
         hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5);
-        hipLaunchKernelGGL((k_median<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN7));
         hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7);
-        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, g_f, b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1);
-        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi);
+        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, g_f, b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, ctx->d_weak);
+        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, ctx->d_weak);
         rc = run_hysteresis(ctx, 0, 0, 1, g_h);
         if (rc) return rc;
         hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES));
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
         {
             const dim3 g_v(g_f.x, g_f.y, nb * NVAR);
-            hipLaunchKernelGGL(k_sobel_nms_planes, g_v, b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo, p->hc_param1, 0);
+            hipLaunchKernelGGL(k_sobel_nms_planes, g_v, b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo, p->hc_param1, 0, ctx->d_weak);
         }
         rc = run_hysteresis(ctx, 1, 1, NVAR, g_h);
         if (rc) return rc;
 
         {
             const dim3 g_vote((wmax + VT - 1) / VT, (hmax + VT - 1) / VT, nb * NVAR);
-            const dim3 g_bins((wmax + EB - 1) / EB, (hmax + EB - 1) / EB, nb * NVAR);
+            const dim3 g_bins((wmax + 4 * EB - 1) / (4 * EB), (hmax + EB - 1) / EB, nb * NVAR);
             hipLaunchKernelGGL(k_edge_bins, g_bins, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
                                ctx->d_bin_ent, ctx->d_bin_cnt);
             hipLaunchKernelGGL(k_vote_centres, g_vote, dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,

@@ -39,6 +39,7 @@ struct Geo {
     int nb;               // images in this pass
     int wmax;
     int bw, bins;         // edge bins per row / per plane (32x32-pixel cells)
+    int tw, tiles;        // 64x32 Canny tiles per row / per plane (hysteresis work flags)
     long long slot;       // pitch * hmax
 };
 

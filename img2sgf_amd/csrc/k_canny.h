@@ -10,13 +10,14 @@ namespace i2s {
 
 constexpr int CT_W = 64;   // NMS output tile
 constexpr int CT_H = 32;
-constexpr int HT = 64;     // hysteresis tile (square)
+// hysteresis works on the same 64 x 32 tiles; weak[(m * nb + b) * g.tiles + ty * g.tw + tx] != 0 iff the tile holds weak pixels
 
 // Sobel + NMS of one tile.  src(y,x,c) = sp[y*sstride + x*CN + c].
 template <int CN>
 __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, int sstride, int w, int h,
-                                               int low, int high, uint8_t* __restrict__ mp, int mpitch)
+                                               int low, int high, uint8_t* __restrict__ mp, int mpitch, int* __restrict__ weak_flag)
 {
+    __shared__ int s_weak;
     constexpr int SW = CT_W + 4, SH = CT_H + 4;   // source tile with 2-px apron
     constexpr int MW = CT_W + 2, MH = CT_H + 2;   // gradient tile with 1-px apron
     __shared__ uint8_t s_src[SH][SW * CN + 4];
@@ -25,6 +26,7 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
+    if (tid == 0) s_weak = 0;
     for (int i = tid; i < SH * SW; i += 256) {
         const int ly = i / SW, lx = i - ly * SW;
         const int gy = iclamp(y0 + ly - 2, 0, h - 1), gx = iclamp(x0 + lx - 2, 0, w - 1);
@@ -79,18 +81,22 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
             if (keep) out = (m > high) ? 2 : 0;
         }
         mp[(size_t)gy * mpitch + gx] = out;
+        if (out == 0) s_weak = 1;
     }
+    __syncthreads();
+    if (tid == 0) *weak_flag = s_weak;
 }
 
 // Main Canny (map 0) on the source image: grid (tiles_x, tiles_y, nb).
 template <int CN>
 __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ map0,
-                                                       int low, int high)
+                                                       int low, int high, int* __restrict__ weak)
 {
     const int b = blockIdx.z;
     const ImgDesc im = desc[b];
     if (im.cn != CN) return;
-    sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, g.pitch);
+    sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, g.pitch,
+                       weak + (size_t)b * g.tiles + (size_t)blockIdx.y * g.tw + blockIdx.x);
 }
 
 // Sobel + NMS on single-channel PLANES, 4 pixels per thread with dword LDS traffic.
@@ -100,8 +106,10 @@ __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict
 // grid (tiles_x, tiles_y, nb * nvariants), block 256, tile 64 x 32 outputs.
 // planes = variant plane 0 base, maps = map 0 base.
 __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
-                                                          uint8_t* __restrict__ maps, int v_first, int low, int high, int main_mode)
+                                                          uint8_t* __restrict__ maps, int v_first, int low, int high, int main_mode,
+                                                          int* __restrict__ weak)
 {
+    __shared__ int s_weak;
     constexpr int SROWS = CT_H + 4, SWORDS = CT_W / 4 + 4, SSTR = SWORDS + 1;   // source rows y0-2.., x0-8 .. x0+72
     constexpr int MROWS = CT_H + 2, MSTRIPS = CT_W / 4 + 2, MSTR = 2 * MSTRIPS + 1;   // mag rows y0-1.., x0-4 .. x0+68 (u16 pairs)
     __shared__ unsigned s_src[SROWS * SSTR];
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     const int tid = threadIdx.x;
     const uint8_t* plane = planes + ((size_t)v * g.nb + b) * g.slot;
     uint8_t* mp = maps + ((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.slot;
+    if (tid == 0) s_weak = 0;
     load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, plane, g.pitch, w, h, x0 - 8, y0 - 2, tid);
     __syncthreads();
     // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry
@@ -169,94 +178,115 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
         unsigned outw = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+            // branch-free NMS: evaluate the three sector rules and select (divergent branches cost more than the ALU work)
             const int mcur = mg[1][q + 1];
-            unsigned o = 1;
-            if (mcur > low) {
-                const int xs = gdx[k][q], ys = gdy[k][q];
-                const int ax = iabs_(xs), ay = iabs_(ys) << 15;
-                const int tg22x = ax * 13573;
-                bool keep;
-                if (ay < tg22x) keep = mcur > mg[1][q] && mcur >= mg[1][q + 2];
-                else {
-                    const int tg67x = tg22x + (ax << 16);
-                    if (ay > tg67x) keep = mcur > mg[0][q + 1] && mcur >= mg[2][q + 1];
-                    else {
-                        const bool neg = (xs ^ ys) < 0;       // s = neg ? -1 : 1 -> compare (row-1, x-s) and (row+1, x+s)
-                        keep = neg ? (mcur > mg[0][q + 2] && mcur > mg[2][q]) : (mcur > mg[0][q] && mcur > mg[2][q + 2]);
-                    }
-                }
-                if (keep) o = (mcur > high) ? 2u : 0u;
-            }
+            const int xs = gdx[k][q], ys = gdy[k][q];
+            const int ax = iabs_(xs), ay = iabs_(ys) << 15;
+            const int tg22x = ax * 13573;
+            const int tg67x = tg22x + (ax << 16);
+            const int c_h = (mcur > mg[1][q]) & (mcur >= mg[1][q + 2]);
+            const int c_v = (mcur > mg[0][q + 1]) & (mcur >= mg[2][q + 1]);
+            // diagonal: s = ((xs ^ ys) < 0) ? -1 : 1 -> compare (row-1, x-s) and (row+1, x+s).  The selection is done with a
+            // bit mask on VALUES (a ?: on array elements gets folded into a dynamic register-array index = an 18-way
+            // select chain).
+            const int msk = (xs ^ ys) >> 31;                // all ones when the signs differ
+            const int ul = mg[0][q], ur = mg[0][q + 2], dl = mg[2][q], dr = mg[2][q + 2];
+            const int d_a = ul ^ ((ul ^ ur) & msk);
+            const int d_b = dr ^ ((dr ^ dl) & msk);
+            const int c_d = (mcur > d_a) & (mcur > d_b);
+            const int keep = (ay < tg22x) ? c_h : ((ay > tg67x) ? c_v : c_d);
+            const unsigned o = ((mcur > low) & keep) ? ((mcur > high) ? 2u : 0u) : 1u;
             outw |= o << (8 * q);
         }
         uint8_t* dstp = mp + (size_t)gy * g.pitch + gx0;
-        if (gx0 + 3 < w) *reinterpret_cast<unsigned*>(dstp) = outw;
-        else for (int q = 0; q < 4 && gx0 + q < w; q++) dstp[q] = (uint8_t)(outw >> (8 * q));
+        bool wk;
+        if (gx0 + 3 < w) {
+            *reinterpret_cast<unsigned*>(dstp) = outw;
+            wk = ((outw - 0x01010101u) & ~outw & 0x80808080u) != 0;      // some byte == 0
+        } else {
+            wk = false;
+            for (int q = 0; q < 4 && gx0 + q < w; q++) { dstp[q] = (uint8_t)(outw >> (8 * q)); wk |= ((outw >> (8 * q)) & 0xffu) == 0; }
+        }
+        if (wk) s_weak = 1;
     }
+    __syncthreads();
+    if (tid == 0) weak[((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)blockIdx.y * g.tw + blockIdx.x] = s_weak;
 }
 
-// One hysteresis pass over maps [m_first, m_first + gridDim.z / nb).  Each block iterates its 64x64 tile
-// (with a read-only 1-px apron) to a local fixed point in LDS; the host launches passes back to back and
-// every pass returns immediately once the previous pass changed nothing (flags[pass-1] == 0).
-// maps points at map 0; map m of image b at (m * nb + b) * slot.
+// One hysteresis pass over maps [m_first, m_first + gridDim.z / nb).  Each block brings its 64x32 tile (with a read-only
+// 1-px apron) to a local fixed point in LDS.  The host launches passes back to back; a pass returns at once when the
+// previous pass changed nothing anywhere (flags[pass-1] == 0), a tile is skipped without touching memory when it holds
+// no weak pixel (flag written by the NMS kernel) or when neither it nor any of its 8 neighbours changed in the previous
+// pass (chg[tile] == index of the last pass that changed it, + 1).  The result is the unique fixed point of "a weak pixel
+// becomes an edge iff an 8-neighbour is an edge", independent of scheduling.
+// maps points at map 0; map m of image b at (m * nb + b) * slot.  grid (tiles_x, tiles_y, nb * nmaps), block 256.
 __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
-                                                    int m_first, int* __restrict__ flags, int pass)
+                                                    int m_first, int* __restrict__ flags, int pass,
+                                                    const int* __restrict__ weak, int* __restrict__ chg)
 {
-    __shared__ uint8_t s_map[HT + 2][HT + 4];
+    constexpr int SROWS = CT_H + 2, SWORDS = CT_W / 4 + 2, SSTR = SWORDS + 1;    // bytes x0-4 .. x0+68, rows y0-1 .. y0+32
+    __shared__ unsigned s_w[SROWS * SSTR];
     __shared__ int s_flag[2];
     if (pass > 0 && flags[pass - 1] == 0) return;
     const int b = blockIdx.z % g.nb;
     const int m = m_first + blockIdx.z / g.nb;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * HT, y0 = blockIdx.y * HT;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
     if (x0 >= w || y0 >= h) return;
+    const size_t tbase = ((size_t)m * g.nb + b) * g.tiles;
+    const int tile = blockIdx.y * g.tw + blockIdx.x;
+    if (weak[tbase + tile] == 0) return;
+    if (pass > 0) {
+        const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
+        bool any = false;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int tx = (int)blockIdx.x + dx, ty = (int)blockIdx.y + dy;
+                if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty && chg[tbase + ty * g.tw + tx] == pass) any = true;
+            }
+        if (!any) return;
+    }
     uint8_t* mp = maps + ((size_t)m * g.nb + b) * g.slot;
     const int tid = threadIdx.x;
     if (tid < 2) s_flag[tid] = 0;
+    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_ONE>(s_w, mp, g.pitch, w, h, x0 - 4, y0 - 1, tid);
     __syncthreads();
-    int weak = 0;
-    for (int i = tid; i < (HT + 2) * (HT + 2); i += 256) {
-        const int ly = i / (HT + 2), lx = i - ly * (HT + 2);
-        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        uint8_t v = 1;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = mp[(size_t)gy * g.pitch + gx];
-        s_map[ly][lx] = v;
-        if (v == 0 && ly >= 1 && ly <= HT && lx >= 1 && lx <= HT) weak = 1;
-    }
-    if (weak) s_flag[0] = 1;
-    __syncthreads();
-    if (s_flag[0] == 0) return;   // no weak pixel in this tile: nothing can change
-    __syncthreads();
-    // thread owns the 4x4 patch at (py, px)
-    const int py = 1 + (tid / 16) * 4, px = 1 + (tid % 16) * 4;
+    uint8_t* s_map = reinterpret_cast<uint8_t*>(s_w);      // byte (row r, column c) at r * 4 * SSTR + c, pixel x0 + c - 4
+    constexpr int BSTR = 4 * SSTR;
+    // thread owns the 4 (wide) x 2 (tall) patch at tile rows py, py+1, byte columns px .. px+3
+    const int py = 1 + (tid / 16) * 2, px = 4 + (tid % 16) * 4;
     bool any_change = false;
-    for (int iter = 0; iter < HT * HT; iter++) {
-        if (tid == 0) s_flag[iter & 1] = 0;
-        __syncthreads();
+    for (int iter = 0; iter < CT_W * CT_H; iter++) {
         bool changed = false;
-        for (int dy = 0; dy < 4; dy++)
+        for (int dy = 0; dy < 2; dy++)
             for (int dx = 0; dx < 4; dx++) {
-                const int y = py + dy, x = px + dx;
-                if (s_map[y][x] != 0) continue;
-                if (s_map[y - 1][x - 1] == 2 || s_map[y - 1][x] == 2 || s_map[y - 1][x + 1] == 2 ||
-                    s_map[y][x - 1] == 2 || s_map[y][x + 1] == 2 ||
-                    s_map[y + 1][x - 1] == 2 || s_map[y + 1][x] == 2 || s_map[y + 1][x + 1] == 2) {
-                    s_map[y][x] = 2;
+                const int o = (py + dy) * BSTR + px + dx;
+                if (s_map[o] != 0) continue;
+                if (s_map[o - BSTR - 1] == 2 || s_map[o - BSTR] == 2 || s_map[o - BSTR + 1] == 2 ||
+                    s_map[o - 1] == 2 || s_map[o + 1] == 2 ||
+                    s_map[o + BSTR - 1] == 2 || s_map[o + BSTR] == 2 || s_map[o + BSTR + 1] == 2) {
+                    s_map[o] = 2;
                     changed = true;
                 }
             }
         if (changed) { s_flag[iter & 1] = 1; any_change = true; }
         __syncthreads();
-        if (s_flag[iter & 1] == 0) break;
+        const int f = s_flag[iter & 1];
+        __syncthreads();
+        if (tid == 0) s_flag[iter & 1] = 0;
+        if (f == 0) break;
     }
     if (any_change) {
-        for (int dy = 0; dy < 4; dy++)
-            for (int dx = 0; dx < 4; dx++) {
-                const int y = py + dy, x = px + dx;
-                const int gy = y0 + y - 1, gx = x0 + x - 1;
-                if (gx < w && gy < h && s_map[y][x] == 2) mp[(size_t)gy * g.pitch + gx] = 2;
-            }
+        for (int dy = 0; dy < 2; dy++) {
+            const int gy = y0 + py + dy - 1;
+            if (gy >= h) continue;
+            const int gx = x0 + px - 4;
+            const unsigned v4 = s_w[(py + dy) * SSTR + px / 4];
+            if (gx + 3 < w) *reinterpret_cast<unsigned*>(mp + (size_t)gy * g.pitch + gx) = v4;
+            else for (int q = 0; q < 4 && gx + q < w; q++) mp[(size_t)gy * g.pitch + gx + q] = (uint8_t)(v4 >> (8 * q));
+        }
         flags[pass] = 1;
+        chg[tbase + tile] = pass + 1;
     }
 }
 

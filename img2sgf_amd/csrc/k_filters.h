@@ -93,15 +93,18 @@ __global__ __launch_bounds__(256) void k_gauss(const ImgDesc* __restrict__ desc,
     }
 }
 
-// ---- K4: exact KxK median, BORDER_REPLICATE.  The median m of n = K*K values is the largest t with
-// #(values < t) <= n/2; built bit by bit (8 counting passes over the window held in registers).
-// 4 pixels per thread; the (K + 3) x K neighbourhood of the strip is read as 3 dwords per row.
-template <int K>
-__global__ __launch_bounds__(256) void k_median(const ImgDesc* __restrict__ desc, Geo g,
-                                                const uint8_t* __restrict__ grey, uint8_t* __restrict__ out)
+// ---- K4: exact medians, BORDER_REPLICATE (cv.medianBlur, img2sgf.py:174).
+__device__ __forceinline__ int imin3(int a, int b, int c) { return imin(imin(a, b), c); }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
+__device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }
+
+// 3x3: sort the three values of every column once (min3 / med3 / max3, shared by the three windows that contain the
+// column), then median = med3( max of the column minima, med of the column medians, min of the column maxima ).
+// 4 pixels per thread, dword LDS traffic.
+__global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ desc, Geo g,
+                                                 const uint8_t* __restrict__ grey, uint8_t* __restrict__ out)
 {
-    constexpr int R = K / 2, N = K * K, HALF = N / 2;
-    constexpr int SROWS = FT_H + 2 * R, SWORDS = FT_W / 4 + 2, SSTR = SWORDS + 1;
+    constexpr int SROWS = FT_H + 2, SWORDS = FT_W / 4 + 2, SSTR = SWORDS + 1;
     constexpr int NS = FT_W / 4;
     __shared__ unsigned s_src[SROWS * SSTR];
     const int b = blockIdx.z;
@@ -109,40 +112,150 @@ __global__ __launch_bounds__(256) void k_median(const ImgDesc* __restrict__ desc
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
-    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - R, tid);
+    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - 1, tid);
     __syncthreads();
     uint8_t* o = out + (size_t)b * g.slot;
     for (int i = tid; i < FT_H * NS; i += 256) {
         const int ly = i / NS, s = i - ly * NS;
         const int x = x0 + 4 * s, y = y0 + ly;
         if (y >= h || x >= w) continue;
-        int p[K][12];
+        int lo[6], mi[6], hi[6];
+        {
+            const unsigned* ps = s_src + ly * SSTR + s;
+            int r[3][6];
 #pragma unroll
-        for (int j = 0; j < K; j++) {
-            const unsigned* ps = s_src + (ly + j) * SSTR + s;
-            const unsigned wa = ps[0], wb = ps[1], wc = ps[2];
+            for (int j = 0; j < 3; j++) unpack6(ps[j * SSTR], ps[j * SSTR + 1], ps[j * SSTR + 2], r[j]);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { p[j][q] = (int)((wa >> (8 * q)) & 0xffu); p[j][4 + q] = (int)((wb >> (8 * q)) & 0xffu); p[j][8 + q] = (int)((wc >> (8 * q)) & 0xffu); }
+            for (int c = 0; c < 6; c++) {
+                lo[c] = imin3(r[0][c], r[1][c], r[2][c]);
+                mi[c] = imed3(r[0][c], r[1][c], r[2][c]);
+                hi[c] = imax3(r[0][c], r[1][c], r[2][c]);
+            }
         }
         unsigned ow = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int m = 0;
-#pragma unroll
-            for (int bit = 7; bit >= 0; bit--) {
-                const int t = m | (1 << bit);
-                int c = 0;
-#pragma unroll
-                for (int j = 0; j < K; j++)
-#pragma unroll
-                    for (int k = 0; k < K; k++) c += (p[j][4 + q - R + k] < t) ? 1 : 0;
-                if (c <= HALF) m = t;
-            }
-            ow |= (unsigned)m << (8 * q);
+            const int a = imax3(lo[q], lo[q + 1], lo[q + 2]);
+            const int m = imed3(mi[q], mi[q + 1], mi[q + 2]);
+            const int c = imin3(hi[q], hi[q + 1], hi[q + 2]);
+            ow |= (unsigned)imed3(a, m, c) << (8 * q);
         }
         uint8_t* dp = o + (size_t)y * g.pitch + x;
         if (x + 3 < w) *reinterpret_cast<unsigned*>(dp) = ow;
         else for (int q = 0; q < 4 && x + q < w; q++) dp[q] = (uint8_t)(ow >> (8 * q));
+    }
+}
+
+// 5x5 and 7x7 together, bit-serial on bit planes.
+// The tile is transposed once into 8 bit planes (one 64-bit word per plane and row, bit i = pixel x0-4+i).  A thread
+// owns 2 adjacent columns and walks down 8 output rows; per plane it keeps the window as a bit mask (7 rows x 7 bits in
+// two dwords, 5 x 5 bits in one) held as a ring of row slots, so moving down one row = one bit-field insert.
+// The median is then read off MSB first: with A = elements still tied with the prefix and nh = elements already known
+// to be larger, bit b of the median is 1 iff popcount(A & P_b) + nh >= N - N/2; A shrinks to the matching half.
+// ~230 integer ops per pixel for both medians instead of ~1200 for per-pixel counting.
+constexpr int MT_W = 56, MT_H = 72, M_RPT = 8;
+constexpr int M_ROWS = MT_H + 6, M_SSTR = 17;
+
+template <int N, int NLO>
+__device__ __forceinline__ unsigned median_planes(const unsigned (&plo)[8], const unsigned (&phi)[8])
+{
+    // N elements: NLO bits in plo, N - NLO bits in phi (phi unused when N == NLO)
+    unsigned alo = NLO >= 32 ? 0xffffffffu : ((1u << NLO) - 1u);
+    unsigned ahi = (N - NLO) > 0 ? ((1u << (N - NLO)) - 1u) : 0u;
+    int nh = 0;
+    unsigned m = 0;
+#pragma unroll
+    for (int bit = 7; bit >= 0; bit--) {
+        const unsigned tl = alo & plo[bit];
+        const unsigned th = (N - NLO) > 0 ? (ahi & phi[bit]) : 0u;
+        int ones = __popc(tl) + nh;
+        if ((N - NLO) > 0) ones += __popc(th);
+        const bool one = ones >= N - N / 2;
+        m = (m << 1) | (one ? 1u : 0u);
+        const unsigned nl = alo ^ tl, nhh = ahi ^ th;
+        alo = one ? tl : nl;
+        if ((N - NLO) > 0) ahi = one ? th : nhh;
+        nh = one ? nh : ones;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
+                                                  uint8_t* __restrict__ out5, uint8_t* __restrict__ out7)
+{
+    __shared__ unsigned s_src[M_ROWS * M_SSTR];
+    __shared__ unsigned long long s_pl[8 * M_ROWS];
+    const int b = blockIdx.z;
+    const int w = desc[b].w, h = desc[b].h;
+    const int x0 = blockIdx.x * MT_W, y0 = blockIdx.y * MT_H;
+    if (x0 >= w || y0 >= h) return;
+    const int tid = threadIdx.x;
+    load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - 3, tid);
+    __syncthreads();
+    {
+        // 8 pixels -> 8 plane bytes (8x8 bit-matrix transpose: output byte p = plane p, bit i = pixel i)
+        uint8_t* plb = reinterpret_cast<uint8_t*>(s_pl);
+        for (int i = tid; i < M_ROWS * 8; i += 256) {
+            const int r = i >> 3, gq = i & 7;
+            unsigned long long x = (unsigned long long)s_src[r * M_SSTR + 2 * gq] | ((unsigned long long)s_src[r * M_SSTR + 2 * gq + 1] << 32);
+            unsigned long long t;
+            t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x = x ^ t ^ (t << 7);
+            t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+            t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+#pragma unroll
+            for (int p = 0; p < 8; p++) plb[((size_t)p * M_ROWS + r) * 8 + gq] = (uint8_t)(x >> (8 * p));
+        }
+    }
+    __syncthreads();
+    if (tid >= 28 * 9) return;
+    const int cg = tid % 28, rg = tid / 28;
+    const int c = 2 * cg, r0 = rg * M_RPT;           // first tile column / output row of this thread
+    if (x0 + c >= w || y0 + r0 >= h) return;
+    unsigned a7lo[2][8], a7hi[2][8], a5[2][8], prev[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) { a7lo[0][p] = a7lo[1][p] = a7hi[0][p] = a7hi[1][p] = a5[0][p] = a5[1][p] = 0; prev[p] = 0; }
+    uint8_t* o5 = out5 + (size_t)b * g.slot;
+    uint8_t* o7 = out7 + (size_t)b * g.slot;
+#pragma unroll
+    for (int t = 0; t < M_RPT + 6; t++) {
+        // source tile row r0 + t enters the 7-row ring (slot t % 7); row r0 + t - 1 enters the 5-row ring (slot (t-1) % 5)
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const unsigned long long rw = s_pl[p * M_ROWS + r0 + t];
+            const unsigned seg = (unsigned)(rw >> (c + 1)) & 0xffu;    // bits of tile columns c-3 .. c+4
+            const int s7 = t % 7;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const unsigned v7 = (seg >> q) & 0x7fu;
+                if (s7 < 4) a7lo[q][p] = (a7lo[q][p] & ~(0x7fu << (7 * s7))) | (v7 << (7 * s7));
+                else a7hi[q][p] = (a7hi[q][p] & ~(0x7fu << (7 * (s7 - 4)))) | (v7 << (7 * (s7 - 4)));
+                if (t >= 1) {
+                    const int s5 = (t - 1) % 5;
+                    const unsigned v5 = (prev[p] >> (q + 1)) & 0x1fu;
+                    a5[q][p] = (a5[q][p] & ~(0x1fu << (5 * s5))) | (v5 << (5 * s5));
+                }
+            }
+            prev[p] = seg;
+        }
+        if (t >= 6) {
+            const int y = y0 + r0 + (t - 6);
+            if (y < h) {
+                unsigned m7[2], m5[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    m7[q] = median_planes<49, 28>(a7lo[q], a7hi[q]);
+                    m5[q] = median_planes<25, 25>(a5[q], a5[q]);
+                }
+                const int x = x0 + c;
+                if (x + 1 < w) {
+                    *reinterpret_cast<unsigned short*>(o5 + (size_t)y * g.pitch + x) = (unsigned short)(m5[0] | (m5[1] << 8));
+                    *reinterpret_cast<unsigned short*>(o7 + (size_t)y * g.pitch + x) = (unsigned short)(m7[0] | (m7[1] << 8));
+                } else {
+                    o5[(size_t)y * g.pitch + x] = (uint8_t)m5[0];
+                    o7[(size_t)y * g.pitch + x] = (uint8_t)m7[0];
+                }
+            }
+        }
     }
 }
 

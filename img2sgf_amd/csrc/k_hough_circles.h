@@ -38,53 +38,68 @@ __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitc
 //   .x = x | y << 16,  .y = (sx & 0xffff) | sy << 16
 // with (sx, sy) = cvRound(d * 1024 / |d|) of its Sobel gradient d (hough.cpp HoughCirclesAccumInvoker), stored in the
 // bin of its 32x32-pixel cell.  The vote kernel then streams only the bins within reach of its accumulator tile.
-// grid (bins_x, bins_y, nb * NVAR), block 256 (4 pixels per thread).
+// grid (ceil(bins_x / 4), bins_y, nb * NVAR), block 256 (16 pixels per thread).
 // bin_cnt[(bv * g.bins) + by * g.bw + bx], bin_ent[... * EB_CAP + k].
 __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ desc, Geo g,
                                                    const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
                                                    uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt)
 {
-    __shared__ int s_n;
+    // one block = 4 horizontally adjacent bins (128 x 32 pixels); one 16-byte map load per thread.  Edge positions are
+    // first compacted into an LDS list so that the gradient work (8 neighbour loads, sqrt, 2 divides) is spread evenly
+    // over the block instead of serialising inside the few threads whose 16 pixels lie on a line.
+    __shared__ unsigned s_list[4 * EB * EB];
+    __shared__ int s_nl;
+    __shared__ int s_n[4];
     const int b = blockIdx.z / NVAR, v = blockIdx.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * EB, y0 = blockIdx.y * EB;
+    const int x0 = blockIdx.x * (4 * EB), y0 = blockIdx.y * EB;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const size_t off = ((size_t)v * g.nb + b) * g.slot;
     const uint8_t* plane = planes + off;
     const uint8_t* map = maps + off;
-    const size_t bin = (size_t)(b * NVAR + v) * g.bins + (size_t)blockIdx.y * g.bw + blockIdx.x;
-    if (tid == 0) s_n = 0;
+    const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)blockIdx.y * g.bw + (size_t)blockIdx.x * 4;
+    if (tid < 4) s_n[tid] = 0;
+    if (tid == 4) s_nl = 0;
     __syncthreads();
-    // thread -> 4 consecutive pixels of one row (one aligned dword of the map); edges are sparse (a few %), so the
-    // 3x3 neighbourhood of an edge pixel is fetched straight from the plane (L2) instead of staging the whole tile
-    const int ly = tid >> 3, lx4 = (tid & 7) * 4;
-    const int y = y0 + ly;
-    uint2* out = bin_ent + bin * EB_CAP;
-    if (y < h && x0 + lx4 < w) {
-        const unsigned m4 = *reinterpret_cast<const unsigned*>(map + (size_t)y * g.pitch + x0 + lx4);
-        const unsigned t = m4 ^ 0x02020202u;
-        if (((t - 0x01010101u) & ~t & 0x80808080u) != 0) {      // some byte == 2
+    {
+        const int ly = tid >> 3, c16 = (tid & 7) * 16;
+        const int y = y0 + ly, xs = x0 + c16;
+        if (y < h && xs < w) {
+            const uint4 m16 = *reinterpret_cast<const uint4*>(map + (size_t)y * g.pitch + xs);
+            const unsigned mw[4] = {m16.x, m16.y, m16.z, m16.w};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int x = x0 + lx4 + q;
-                if (x < w && ((m4 >> (8 * q)) & 0xffu) == 2u) {
-                    int dx, dy;
-                    sobel_at(plane, g.pitch, w, h, x, y, dx, dy);
-                    if (dx == 0 && dy == 0) continue;
-                    const float vx = (float)dx, vy = (float)dy;
-                    const float mag = sqrtf(vx * vx + vy * vy);
-                    if (mag < 1.0f) continue;
-                    const int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
-                    const int sy = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
-                    const int k = atomicAdd(&s_n, 1);
-                    out[k] = make_uint2((unsigned)x | ((unsigned)y << 16), ((unsigned)sx & 0xffffu) | ((unsigned)sy << 16));
+            for (int d = 0; d < 4; d++) {
+                const unsigned m4 = mw[d];
+                const unsigned t = m4 ^ 0x02020202u;
+                if (((t - 0x01010101u) & ~t & 0x80808080u) == 0) continue;      // no byte == 2
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int x = xs + 4 * d + q;
+                    if (x < w && ((m4 >> (8 * q)) & 0xffu) == 2u) s_list[atomicAdd(&s_nl, 1)] = (unsigned)x | ((unsigned)y << 16);
                 }
             }
         }
     }
     __syncthreads();
-    if (tid == 0) bin_cnt[bin] = s_n;
+    const int nl = s_nl;
+    for (int i = tid; i < nl; i += 256) {
+        const unsigned e = s_list[i];
+        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+        int dx, dy;
+        sobel_at(plane, g.pitch, w, h, x, y, dx, dy);
+        if (dx == 0 && dy == 0) continue;
+        const float vx = (float)dx, vy = (float)dy;
+        const float mag = sqrtf(vx * vx + vy * vy);
+        if (mag < 1.0f) continue;
+        const int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
+        const int sy = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
+        const int kb = (x - x0) / EB;
+        const int k = atomicAdd(&s_n[kb], 1);
+        bin_ent[(bin0 + kb) * EB_CAP + k] = make_uint2(e, ((unsigned)sx & 0xffffu) | ((unsigned)sy << 16));
+    }
+    __syncthreads();
+    if (tid < 4 && x0 + tid * EB < w) bin_cnt[bin0 + tid] = s_n[tid];
 }
 
 // grid (tiles_x, tiles_y, nb * NVAR), block 512.
@@ -129,17 +144,34 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
     const int r = dir ? -(min_r + st) : (min_r + st);
     const size_t bin_base = (size_t)bv * g.bins;
     // one wavefront per bin: a coalesced 512-byte load brings 64 edge records, every lane tests whether ITS record's
-    // ray segment (+-max_r steps) can touch the tile at all, then the wave walks the surviving records one by one.
-    for (int q = wave; q < nbin; q += VTHREADS / 64) {
-        const int by = by0 + q / nbx, bx = bx0 + q % nbx;
-        const size_t bin = bin_base + (size_t)by * g.bw + bx;
-        const int n = bin_cnt[bin];
-        const uint2* ent = bin_ent + bin * EB_CAP;
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            uint2 mine = make_uint2(0u, 0u);
+    // ray segment (+-max_r steps) can touch the tile at all, then the wave walks the surviving records one by one
+    // (record broadcast through v_readlane, i.e. in scalar registers).  Bin counts are fetched once (lane q holds bin q's
+    // count; the reach window spans at most 7 x 7 bins) and the next bin's records are prefetched during the walk.
+    int my_cnt = 0;
+    if (lane < nbin) my_cnt = bin_cnt[bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx)];
+    int q = wave;
+    int n_cur = 0;
+    const uint2* ent_cur = bin_ent;
+    uint2 mine = make_uint2(0u, 0u);
+    if (q < nbin) {
+        n_cur = __builtin_amdgcn_readlane(my_cnt, q);
+        ent_cur = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+        if (lane < n_cur) mine = ent_cur[lane];
+    }
+    while (q < nbin) {
+        const int qn = q + VTHREADS / 64;
+        int n_next = 0;
+        const uint2* ent_next = bin_ent;
+        uint2 mine_next = make_uint2(0u, 0u);
+        if (qn < nbin) {
+            n_next = __builtin_amdgcn_readlane(my_cnt, qn);
+            ent_next = bin_ent + (bin_base + (size_t)(by0 + qn / nbx) * g.bw + (bx0 + qn % nbx)) * EB_CAP;
+            if (lane < n_next) mine_next = ent_next[lane];
+        }
+        for (int k0 = 0; k0 < n_cur; k0 += 64) {
+            if (k0 > 0) { mine = make_uint2(0u, 0u); if (k0 + lane < n_cur) mine = ent_cur[k0 + lane]; }
             bool reach = false;
-            if (k0 + lane < n) {
-                mine = ent[k0 + lane];
+            if (k0 + lane < n_cur) {
                 const int ex = (int)(mine.x & 0xffffu), ey = (int)(mine.x >> 16);
                 const int sx = (int)(short)(mine.y & 0xffffu), sy = (int)(short)(mine.y >> 16);
                 // the 2 * nsteps vote cells lie within +-(max_r * |s| >> 10) + 1 of the pixel on each axis
@@ -150,7 +182,8 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
             while (m) {
                 const int j = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
-                const unsigned exy = __shfl(mine.x, j), es = __shfl(mine.y, j);
+                const unsigned exy = (unsigned)__builtin_amdgcn_readlane((int)mine.x, j);
+                const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)mine.y, j);
                 if (!act) continue;
                 const int sx = (int)(short)(es & 0xffffu), sy = (int)(short)(es >> 16);
                 const int x2 = ((int)(exy & 0xffffu) * 1024 + r * sx) >> 10;
@@ -162,6 +195,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
                 }
             }
         }
+        q = qn; n_cur = n_next; ent_cur = ent_next; mine = mine_next;
     }
     __syncthreads();
     // centre candidates: cells (x,y), 1 <= x <= w-1, 1 <= y <= h-1 (OpenCV scans padded rows 1..H, cols 1..W

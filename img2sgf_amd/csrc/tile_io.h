@@ -6,13 +6,13 @@
 
 namespace i2s {
 
-enum { BORDER_REPL = 0, BORDER_R101 = 1 };
+enum { BORDER_REPL = 0, BORDER_R101 = 1, BORDER_ONE = 2 };   // BORDER_ONE: bytes outside the image read as 1
 
 template <int MODE>
 __device__ __forceinline__ int border_idx(int p, int n)
 {
-    if (MODE == BORDER_REPL) return iclamp(p, 0, n - 1);
-    return reflect101(p, n);
+    if (MODE == BORDER_R101) return reflect101(p, n);
+    return iclamp(p, 0, n - 1);
 }
 
 // dst[r * DSTRIDE + c] = dword holding plane bytes (xa + 4c .. xa + 4c + 3, ya + r) with border handling.
@@ -23,8 +23,22 @@ __device__ __forceinline__ void load_tile_words(unsigned* __restrict__ dst, cons
 {
     for (int i = tid; i < ROWS * WORDS; i += NT) {
         const int r = i / WORDS, c = i - r * WORDS;
-        const int gy = border_idx<MODE>(ya + r, h);
         const int x = xa + 4 * c;
+        if (MODE == BORDER_ONE) {
+            const int gy1 = ya + r;
+            unsigned v1 = 0x01010101u;
+            if (gy1 >= 0 && gy1 < h) {
+                const uint8_t* row1 = plane + (size_t)gy1 * pitch;
+                if (x >= 0 && x + 3 < w) v1 = *reinterpret_cast<const unsigned*>(row1 + x);
+                else {
+                    v1 = 0;
+                    for (int q = 0; q < 4; q++) v1 |= (unsigned)((x + q >= 0 && x + q < w) ? row1[x + q] : 1) << (8 * q);
+                }
+            }
+            dst[r * DSTRIDE + c] = v1;
+            continue;
+        }
+        const int gy = border_idx<MODE>(ya + r, h);
         const uint8_t* row = plane + (size_t)gy * pitch;
         unsigned v;
         if (x >= 0 && x + 3 < w) {

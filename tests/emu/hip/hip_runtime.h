@@ -98,6 +98,8 @@ template <class T> static inline T __shfl(T v, int src)
 }
 template <class T> static inline T __shfl_down(T v, unsigned d) { return __shfl(v, hipemu::cur->lane + (int)d < 64 ? hipemu::cur->lane + (int)d : hipemu::cur->lane); }
 template <class T> static inline T __shfl_xor(T v, int m) { return __shfl(v, hipemu::cur->lane ^ m); }
+// wave-uniform lane select (v_readlane_b32): all live lanes call it with the same lane index
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
 static inline int __lane_id() { return hipemu::cur->lane; }
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
