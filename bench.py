@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("I2S_BENCH_BATCH", 1024)), help="diagrams per rank per step")
     ap.add_argument("--pass-size", type=int, default=int(os.environ.get("I2S_BENCH_PASS", 128)), help="diagrams per device pass")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("I2S_BENCH_STREAMS", 1)), help="HIP streams (contexts) per GPU")
     ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -49,7 +50,7 @@ def main():
     import torch
     import torch.distributed as dist
     from img2sgf_amd import synth, dist as i2s_dist
-    from img2sgf_amd.pipeline import Detector, Params
+    from img2sgf_amd.pipeline import Detector, Params, StreamedDetector
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -63,7 +64,10 @@ def main():
     imgs, occs = synth.synth_batch(range(lo, hi))
     dev = torch.from_numpy(imgs).cuda(local)
     del imgs
-    det = Detector(local, min(args.pass_size, B), 1024, 1024)
+    if args.streams > 1:
+        det = StreamedDetector(local, args.streams, min(args.pass_size, B), 1024, 1024)
+    else:
+        det = Detector(local, min(args.pass_size, B), 1024, 1024)
     params = Params()
 
     def step():
@@ -102,7 +106,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU, device-resident, full "
-                                   "hot path incl. board all-gather" % B, "pass_size": det.max_batch,
+                                   "hot path incl. board all-gather" % B, "pass_size": det.max_batch, "streams": args.streams,
                        "boards_match_generator": ok},
             "roofline": {"bound": "hbm", "kernel": "blur+Canny stage (k_grey, k_median<3,5,7>, k_gauss<3,5,7>, k_sobel_nms_src, k_hysteresis, k_edges_from_map)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -24,7 +24,7 @@ def needs_build():
 def build(force=False, verbose=False):
     """hipcc cross-compiles without a GPU; returns the path of the shared library."""
     if force or needs_build():
-        cmd = ["hipcc"] + FLAGS + ["-o", LIB, os.path.join(CSRC, "i2s_api.hip")]
+        cmd = ["hipcc"] + FLAGS + os.environ.get("I2S_EXTRA_FLAGS", "").split() + ["-o", LIB, os.path.join(CSRC, "i2s_api.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -154,8 +154,7 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
             R->found_grid = (nh > 0 && nv > 0) ? 1 : 0;
             R->valid_grid = 0; R->board_ready = 0; R->hsize = 0; R->vsize = 0;
             R->n_hcomplete = 0; R->n_vcomplete = 0; R->hspace = 0; R->vspace = 0;
-            int nck = R->n_circles;
-            for (int i = 0; i < R->n_circles; i++) R->circle_kept[i] = 1;   // validate_grid failure returns `circles` unfiltered (:426)
+            s_i[4] = 0;                                            // 1 -> apply the radius filter (valid grid)
             if (status == 0) {
                 // validate_grid (:420-445): horizontal lines first
                 int first = 0, m = 0;
@@ -177,14 +176,9 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
                         const int vsize = mh, hsize = mv;    // number of horizontal lines = vertical size (:435-436)
                         const double hspace = (R->hcentres_complete[mh - 1] - R->hcentres_complete[0]) / (double)vsize;
                         const double vspace = (R->vcentres_complete[mv - 1] - R->vcentres_complete[0]) / (double)hsize;
-                        const double lo = (hspace < vspace ? hspace : vspace) * 0.3;
-                        const double hi = (hspace > vspace ? hspace : vspace) * 0.65;
-                        nck = 0;
-                        for (int i = 0; i < R->n_circles; i++) {
-                            const double r = (double)R->circles[i][2];
-                            const int keep = (lo < r && r < hi) ? 1 : 0;
-                            R->circle_kept[i] = (uint8_t)keep; nck += keep;
-                        }
+                        s_tmp[0][0] = (hspace < vspace ? hspace : vspace) * 0.3;     // min_circle_size (:441)
+                        s_tmp[0][1] = (hspace > vspace ? hspace : vspace) * 0.65;    // max_circle_size (:442)
+                        s_i[4] = 1;
                         R->valid_grid = 1; R->vsize = vsize; R->hsize = hsize;
                         R->n_hcomplete = mh; R->n_vcomplete = mv; R->hspace = hspace; R->vspace = vspace;
                         if (hsize > I2S_BOARD_SIZE) status = I2S_ST_TOO_MANY_VLINES;
@@ -192,9 +186,25 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
                     }
                 }
             }
-            R->n_circles_kept = nck;
             R->status = status;
+            s_i[5] = 0;
         }
+        __syncthreads();
+        {
+            // radius filter (:443), all threads; a failed validation returns `circles` unfiltered (:426)
+            const bool filt = s_i[4] != 0;
+            const double lo = s_tmp[0][0], hi = s_tmp[0][1];
+            int mine = 0;
+            for (int i = tid; i < R->n_circles; i += 256) {
+                int keep = 1;
+                if (filt) { const double r = (double)R->circles[i][2]; keep = (lo < r && r < hi) ? 1 : 0; }
+                R->circle_kept[i] = (uint8_t)keep;
+                mine += keep;
+            }
+            if (mine) atomicAdd(&s_i[5], mine);
+        }
+        __syncthreads();
+        if (tid == 0) R->n_circles_kept = s_i[5];
         __syncthreads();
     }
     // identify_board (:497-543)

@@ -15,7 +15,7 @@ namespace i2s {
 
 constexpr int VT = 126;          // accumulator cells per tile side (interior)
 constexpr int VL = VT + 2;       // LDS tile side incl. apron
-constexpr int VASTR = 130;       // tile row stride in 16-bit cells: 65 dwords == 1 (mod 32 banks), so vertical rays spread over banks
+constexpr int VASTR = 129;       // dword row stride of the LDS tile (odd: vertical rays spread over the banks)
 constexpr int VTHREADS = 512;
 constexpr int EB = 32;           // edge bins: EB x EB pixel cells
 constexpr int EB_CAP = EB * EB;  // worst case: every pixel of a bin is an edge
@@ -112,21 +112,24 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
 // takes one edge record per round, lane = direction * nsteps + step.  The 2-D accumulator never exists in HBM: each
 // workgroup owns 126x126 cells (+1-cell apron) in LDS and tests the 4-neighbour local-maximum rule in place.
 // Cell counts are 16-bit halves of LDS dwords: a cell receives at most 3 votes from each of the < 3100 edge pixels
-// within max_r <= 30 of it, so a half never carries into its neighbour.
+// within max_r <= 30 of it, so a half never carries into its neighbour.  The two halves of a dword are cells 64 rows
+// apart, so the <= 31 consecutive cells of one ray never share a dword (no same-address serialisation of the atomics).
+// (Measured: plain 32-bit cells halve the resident workgroups per CU and run 1.5x slower; a branch-free variant that
+// lets out-of-tile lanes add 0 to clamped cells runs 1.4x slower because of same-address conflicts.)
 __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict__ desc, Geo g,
                                                       const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
                                                       int min_r, int max_r, int acc_thr,
                                                       unsigned* __restrict__ cent_list, int* __restrict__ cent_count,
                                                       int* __restrict__ dbg_acc)
 {
-    __shared__ unsigned s_acc[VL * VASTR / 2];
+    __shared__ unsigned s_acc[(VL / 2) * VASTR];
     const int b = blockIdx.z / NVAR, v = blockIdx.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
     const int cx0 = blockIdx.x * VT, cy0 = blockIdx.y * VT;    // first interior cell
     if (cx0 >= w || cy0 >= h) return;
     const int tid = threadIdx.x;
     const int bv = b * NVAR + v;
-    for (int i = tid; i < VL * VASTR / 2; i += VTHREADS) s_acc[i] = 0;
+    for (int i = tid; i < (VL / 2) * VASTR; i += VTHREADS) s_acc[i] = 0;
     __syncthreads();
     // LDS tile covers cells [lx0, lx0 + VL) x [ly0, ly0 + VL); edge pixels within max_r of it can vote into it
     const int lx0 = cx0 - 1, ly0 = cy0 - 1;
@@ -136,84 +139,103 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
     // cells of this tile that exist in the image: one unsigned compare per axis covers "inside image" and "inside tile"
     const int vx_lo = imax(lx0, 0), vy_lo = imax(ly0, 0);
     const unsigned vx_n = (unsigned)(imin(lx0 + VL, w) - vx_lo), vy_n = (unsigned)(imin(ly0 + VL, h) - vy_lo);
+    const int offx = vx_lo - lx0, offy = vy_lo - ly0;      // valid-cell origin inside the LDS tile (0 or 1)
     const int nsteps = max_r - min_r + 1;          // <= 31
     const int lane = tid & 63, wave = tid >> 6;
     const int dir = lane >= nsteps ? 1 : 0;
     const int st = lane - dir * nsteps;
     const bool act = st < nsteps;                  // lanes 2 * nsteps .. 63 idle
     const int r = dir ? -(min_r + st) : (min_r + st);
+    const unsigned vx_na = act ? vx_n : 0u;        // idle lanes never pass the range test
     const size_t bin_base = (size_t)bv * g.bins;
     // one wavefront per bin: a coalesced 512-byte load brings 64 edge records, every lane tests whether ITS record's
     // ray segment (+-max_r steps) can touch the tile at all, then the wave walks the surviving records one by one
-    // (record broadcast through v_readlane, i.e. in scalar registers).  Bin counts are fetched once (lane q holds bin q's
-    // count; the reach window spans at most 7 x 7 bins) and the next bin's records are prefetched during the walk.
+    // (record broadcast through v_readlane, i.e. in scalar registers).  The reach window spans at most 7 x 7 bins, so a
+    // wave owns at most 7 of them: their counts come from one lane-indexed load and the first 64 records of ALL of them
+    // are requested up front, so the memory latency is paid once per workgroup, not once per bin.
+    constexpr int WB = 7;                                   // ceil(49 / 8) bins per wave
     int my_cnt = 0;
     if (lane < nbin) my_cnt = bin_cnt[bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx)];
-    int q = wave;
-    int n_cur = 0;
-    const uint2* ent_cur = bin_ent;
-    uint2 mine = make_uint2(0u, 0u);
-    if (q < nbin) {
-        n_cur = __builtin_amdgcn_readlane(my_cnt, q);
-        ent_cur = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
-        if (lane < n_cur) mine = ent_cur[lane];
-    }
-    while (q < nbin) {
-        const int qn = q + VTHREADS / 64;
-        int n_next = 0;
-        const uint2* ent_next = bin_ent;
-        uint2 mine_next = make_uint2(0u, 0u);
-        if (qn < nbin) {
-            n_next = __builtin_amdgcn_readlane(my_cnt, qn);
-            ent_next = bin_ent + (bin_base + (size_t)(by0 + qn / nbx) * g.bw + (bx0 + qn % nbx)) * EB_CAP;
-            if (lane < n_next) mine_next = ent_next[lane];
+    uint2 pre[WB];
+    int cnt[WB];
+#pragma unroll
+    for (int i = 0; i < WB; i++) {
+        const int q = wave + i * (VTHREADS / 64);
+        pre[i] = make_uint2(0u, 0u);
+        cnt[i] = 0;
+        if (q < nbin) {
+            cnt[i] = __builtin_amdgcn_readlane(my_cnt, q);
+            const uint2* ent = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+            if (lane < cnt[i]) pre[i] = ent[lane];
         }
+    }
+#pragma unroll
+    for (int i = 0; i < WB; i++) {
+        const int q = wave + i * (VTHREADS / 64);
+        const int n_cur = cnt[i];
+        if (q >= nbin || n_cur == 0) continue;
+        const uint2* ent_cur = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+        uint2 mine = pre[i];
         for (int k0 = 0; k0 < n_cur; k0 += 64) {
             if (k0 > 0) { mine = make_uint2(0u, 0u); if (k0 + lane < n_cur) mine = ent_cur[k0 + lane]; }
+            // lane-parallel: unpack MY record (position relative to the first valid cell in 1/1024 px, step vector) and
+            // test whether its ray segment can touch the tile; the walk below then needs no scalar unpacking at all
+            // (the scalar ALU is shared by the CU's four SIMDs and was the bottleneck of this loop).
+            const int sxv = (int)(short)(mine.y & 0xffffu), syv = (int)(short)(mine.y >> 16);
+            const int exr = (int)(mine.x & 0xffffu) - vx_lo, eyr = (int)(mine.x >> 16) - vy_lo;
+            const int X0v = exr << 10, Y0v = eyr << 10;
             bool reach = false;
             if (k0 + lane < n_cur) {
-                const int ex = (int)(mine.x & 0xffffu), ey = (int)(mine.x >> 16);
-                const int sx = (int)(short)(mine.y & 0xffffu), sy = (int)(short)(mine.y >> 16);
                 // the 2 * nsteps vote cells lie within +-(max_r * |s| >> 10) + 1 of the pixel on each axis
-                const int ddx = ((max_r * iabs_(sx)) >> 10) + 1, ddy = ((max_r * iabs_(sy)) >> 10) + 1;
-                reach = ex + ddx >= vx_lo && ex - ddx < vx_lo + (int)vx_n && ey + ddy >= vy_lo && ey - ddy < vy_lo + (int)vy_n;
+                const int ddx = ((max_r * iabs_(sxv)) >> 10) + 1, ddy = ((max_r * iabs_(syv)) >> 10) + 1;
+                reach = exr + ddx >= 0 && exr - ddx < (int)vx_n && eyr + ddy >= 0 && eyr - ddy < (int)vy_n;
             }
             unsigned long long m = __ballot(reach);
+#ifdef I2S_EXP_NOWALK
+            if (cent_count != nullptr) m = 0;
+#endif
             while (m) {
-                const int j = __ffsll((unsigned long long)m) - 1;
-                m &= m - 1;
-                const unsigned exy = (unsigned)__builtin_amdgcn_readlane((int)mine.x, j);
-                const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)mine.y, j);
-                if (!act) continue;
-                const int sx = (int)(short)(es & 0xffffu), sy = (int)(short)(es >> 16);
-                const int x2 = ((int)(exy & 0xffffu) * 1024 + r * sx) >> 10;
-                const int y2 = ((int)(exy >> 16) * 1024 + r * sy) >> 10;
-                const unsigned tx = (unsigned)(x2 - vx_lo), ty = (unsigned)(y2 - vy_lo);
-                if (tx < vx_n && ty < vy_n) {
-                    const unsigned idx = (unsigned)(y2 - ly0) * VASTR + (unsigned)(x2 - lx0);
-                    atomicAdd(&s_acc[idx >> 1], 1u << ((idx & 1u) * 16));
+                const int j = __builtin_ctzll(m);
+                m &= ~(1ull << j);
+                const int X0 = __builtin_amdgcn_readlane(X0v, j), Y0 = __builtin_amdgcn_readlane(Y0v, j);
+                const int sx = __builtin_amdgcn_readlane(sxv, j), sy = __builtin_amdgcn_readlane(syv, j);
+                // r * s fits 24 bits (|r| <= 31, |s| <= 1024): one full-rate v_mad_i32_i24 + shift + unsigned compare per axis
+                const unsigned tx = (unsigned)((X0 + __mul24(r, sx)) >> 10);
+                const unsigned ty = (unsigned)((Y0 + __mul24(r, sy)) >> 10);
+#ifdef I2S_EXP_NOLOOP
+                if (tx == 0x7fffffffu) {
+#elif defined(I2S_EXP_NOATOMIC)
+                if (tx < vx_na && ty < vy_n && cent_count == nullptr) {
+#else
+                if (tx < vx_na && ty < vy_n) {
+#endif
+                    const unsigned cy = ty + (unsigned)offy;
+                    atomicAdd(&s_acc[(cy & 63u) * (unsigned)VASTR + tx + (unsigned)offx], (cy & 64u) ? 0x10000u : 1u);
                 }
             }
         }
-        q = qn; n_cur = n_next; ent_cur = ent_next; mine = mine_next;
     }
     __syncthreads();
     // centre candidates: cells (x,y), 1 <= x <= w-1, 1 <= y <= h-1 (OpenCV scans padded rows 1..H, cols 1..W
     // of an accumulator whose votes sit at unpadded indices; cells x == W or y == H hold no votes).
-    const unsigned short* acc16 = reinterpret_cast<const unsigned short*>(s_acc);
+    // tile cell (cx, cy): 16-bit half (cy >> 6) of dword (cy & 63) * VASTR + cx
+#define I2S_CELL(cx, cy) ((int)((s_acc[((cy) & 63) * VASTR + (cx)] >> (((cy) >> 6) * 16)) & 0xffffu))
+#ifdef I2S_EXP_NOCENTRE
+    if (cent_count != nullptr) return;
+#endif
     for (int i = tid; i < VT * VT; i += VTHREADS) {
         const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
         const int x = lx0 + tx, y = ly0 + ty;
         if (x >= w || y >= h) continue;
-        const int a = acc16[ty * VASTR + tx];
+        const int a = I2S_CELL(tx, ty);
         if (dbg_acc) dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = a;
-        if (x < 1 || y < 1) continue;
-        if (a > acc_thr && a > (int)acc16[ty * VASTR + tx - 1] && a >= (int)acc16[ty * VASTR + tx + 1] &&
-            a > (int)acc16[(ty - 1) * VASTR + tx] && a >= (int)acc16[(ty + 1) * VASTR + tx]) {
+        if (a <= acc_thr || x < 1 || y < 1) continue;
+        if (a > I2S_CELL(tx - 1, ty) && a >= I2S_CELL(tx + 1, ty) && a > I2S_CELL(tx, ty - 1) && a >= I2S_CELL(tx, ty + 1)) {
             const int k = atomicAdd(&cent_count[bv], 1);
             if (k < CENT_CAP) cent_list[(size_t)bv * CENT_CAP + k] = (unsigned)x | ((unsigned)y << 16);
         }
     }
+#undef I2S_CELL
 }
 
 // Sort key of an estimated circle; ascending key order == OpenCV's cmpAccum order
@@ -260,26 +282,40 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
             const unsigned e = cent_list[(size_t)bv * CENT_CAP + c];
             cxi = (int)(e & 0xffffu); cyi = (int)(e >> 16);
             const float cx = ((float)cxi + 0.5f) * 1.0f, cy = ((float)cyi + 0.5f) * 1.0f;
-            // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: bins overlapping that box
+            // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: at most 3 x 3 bins overlap that box.
+            // Lane q fetches bin q's count, then all record loads of all bins are issued before any is consumed.
             const int bx0 = imax(cxi - max_r, 0) / EB, bx1 = imin(cxi + max_r + 1, w - 1) / EB;
             const int by0 = imax(cyi - max_r, 0) / EB, by1 = imin(cyi + max_r + 1, h - 1) / EB;
-            for (int by = by0; by <= by1; by++)
-                for (int bx = bx0; bx <= bx1; bx++) {
-                    const size_t bin = bin_base + (size_t)by * g.bw + bx;
-                    const int cnt = bin_cnt[bin];
-                    const uint2* ent = bin_ent + bin * EB_CAP;
-                    for (int k = lane; k < cnt; k += 64) {
-                        const unsigned xy = ent[k].x;
-                        const float ddx = cx - (float)(int)(xy & 0xffffu), ddy = cy - (float)(int)(xy >> 16);
-                        const float r2 = ddx * ddx + ddy * ddy;
-                        if (minR2 <= r2 && r2 <= maxR2) {
-                            const float d = sqrtf(r2);
-                            int bi = __float2int_rn((d - (float)min_r) / 1.0f * (float)nBinsPerDr);
-                            bi = imax(0, imin(nBins - 1, bi));
-                            atomicAdd(&bins[bi], 1);
-                        }
+            const int nbx = bx1 - bx0 + 1, nbin = nbx * (by1 - by0 + 1);        // <= 9
+            int my_cnt = 0;
+            if (lane < nbin) my_cnt = bin_cnt[bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx)];
+            unsigned pre[9];
+            int cnt[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                pre[q] = 0xffffffffu; cnt[q] = 0;
+                if (q < nbin) {
+                    cnt[q] = __builtin_amdgcn_readlane(my_cnt, q);
+                    const uint2* ent = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+                    if (lane < cnt[q]) pre[q] = ent[lane].x;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                if (q >= nbin) continue;
+                const uint2* ent = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+                for (int k = lane; k < cnt[q]; k += 64) {
+                    const unsigned xy = k < 64 ? pre[q] : ent[k].x;
+                    const float ddx = cx - (float)(int)(xy & 0xffffu), ddy = cy - (float)(int)(xy >> 16);
+                    const float r2 = ddx * ddx + ddy * ddy;
+                    if (minR2 <= r2 && r2 <= maxR2) {
+                        const float d = sqrtf(r2);
+                        int bi = __float2int_rn((d - (float)min_r) / 1.0f * (float)nBinsPerDr);
+                        bi = imax(0, imin(nBins - 1, bi));
+                        atomicAdd(&bins[bi], 1);
                     }
                 }
+            }
         }
         __syncthreads();
         // inclusive prefix sums P[i] (in place) and occupancy masks, 64 bins per step

@@ -243,6 +243,42 @@ class Detector:
         return dict(blur_canny_ms=ms[0], hough_circles_ms=ms[1], erase_lines_ms=ms[2], grid_ms=ms[3], total_ms=ms[4])
 
 
+class StreamedDetector:
+    """n_streams independent contexts (one HIP stream + workspace each) on one GPU, driven from n_streams host threads
+    (ctypes releases the GIL during the C call).  A device-resident batch is split into contiguous slices, one per
+    stream, so the latency-bound tail kernels of one slice (grid repair, sorting, peak search) overlap with the
+    throughput-bound kernels of another."""
+
+    def __init__(self, device=0, n_streams=2, max_batch=64, max_w=1024, max_h=1024, lib=None):
+        from concurrent.futures import ThreadPoolExecutor
+        self.dets = [Detector(device, max_batch, max_w, max_h, lib=lib) for _ in range(n_streams)]
+        self.pool = ThreadPoolExecutor(max_workers=n_streams)
+        self.max_batch = max_batch
+
+    def detect_device(self, batch, params: Optional[Params] = None):
+        n = len(self.dets)
+        B = batch.shape[0]
+        cuts = [B * i // n for i in range(n + 1)]
+        futs = [self.pool.submit(self.dets[i].detect_device, batch[cuts[i]:cuts[i + 1]], params)
+                for i in range(n) if cuts[i + 1] > cuts[i]]
+        out = (I2sBoard * B)()
+        pos = 0
+        for f in futs:
+            part = f.result()
+            C.memmove(C.byref(out, pos * C.sizeof(I2sBoard)), part, C.sizeof(part))
+            pos += len(part)
+        return out
+
+    def last_timing(self):
+        t = [d.last_timing() for d in self.dets]
+        return {k: sum(x[k] for x in t) for k in t[0]}
+
+    def close(self):
+        for d in self.dets:
+            d.close()
+        self.pool.shutdown()
+
+
 _default_detector = None
 
 

@@ -107,6 +107,8 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline int __mul24(int a, int b) { return a * b; }
+static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }
 static inline int __double2int_rn(double v) { return (int)lrint(v); }
 
