@@ -2,8 +2,14 @@
 """Benchmark of the board-detection hot path: go-diagram images/sec (1024x1024 greyscale) on N MI355X.
 
 A step = one pass of the whole hot path (grey -> blur bank -> Canny -> 10x HoughCircles -> erase -> HoughLines ->
-grid -> classifier) over one batch of synthetic diagrams resident in HBM, per rank; ranks own disjoint seed
-ranges (no data-path collective), then all-gather the 384-byte board records over RCCL.  Prints one JSON line.
+grid -> classifier) over one batch of synthetic diagrams resident in HBM, per rank; ranks own disjoint seed ranges
+(no data-path collective), then all-gather the 384-byte board records over RCCL.  Prints one JSON line.
+
+Workload (BASELINE.json configs[2]): 4096 synthetic 1024x1024 19x19 diagrams per GPU, seeds rank*4096 .. +4095.
+The timed region drives `--streams` HIP streams per GPU (independent contexts; the latency-bound tail kernels of one
+slice overlap the throughput-bound kernels of another).  The roofline object is measured separately, right after the
+timed region, on ONE stream (concurrent streams would stretch every per-kernel duration): HIP events recorded on the
+context's stream around the blur+Canny stage, `--roofline-images` diagrams of the same workload.
 """
 import argparse
 import json
@@ -32,7 +38,17 @@ def cpu_baseline(n_images):
         opipe.process_image(im, keep_planes=False)
     dt = time.perf_counter() - t0
     return dict(value=n_images / dt, unit="images/s", cores=1, kind="port",
-                sample="%d synthetic 1024x1024 diagrams (seeds 0..%d), oracle/ C restatement, 1 thread" % (n_images, n_images - 1))
+                sample="%d synthetic 1024x1024 diagrams (seeds 0..%d), oracle/ C restatement of the reference's OpenCV "
+                       "path (cv2 is not installed), 1 thread" % (n_images, n_images - 1))
+
+
+def measured_traffic():
+    """HBM bytes per image of the blur+Canny stage from the committed PMC passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f).get("blur_canny_hbm_bytes_per_image")
+    return None
 
 
 def main():
@@ -40,9 +56,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("I2S_BENCH_BATCH", 1024)), help="diagrams per rank per step")
-    ap.add_argument("--pass-size", type=int, default=int(os.environ.get("I2S_BENCH_PASS", 128)), help="diagrams per device pass")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("I2S_BENCH_STREAMS", 1)), help="HIP streams (contexts) per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("I2S_BENCH_BATCH", 4096)), help="diagrams per rank per step")
+    ap.add_argument("--pass-size", type=int, default=int(os.environ.get("I2S_BENCH_PASS", 64)), help="diagrams per device pass")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("I2S_BENCH_STREAMS", 3)), help="HIP streams (contexts) per GPU")
+    ap.add_argument("--roofline-images", type=int, default=256)
     ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -61,13 +78,13 @@ def main():
     torch.cuda.set_device(local)
     B = args.batch
     lo, hi = i2s_dist.shard_range(B * world, rank, world)
-    imgs, occs = synth.synth_batch(range(lo, hi))
-    dev = torch.from_numpy(imgs).cuda(local)
-    del imgs
+    dev, occs = synth.synth_batch_torch(range(lo, hi), torch.device("cuda", local))   # rendered on the GPU, resident in HBM
+    torch.cuda.synchronize()
+    pass_size = min(args.pass_size, B)
     if args.streams > 1:
-        det = StreamedDetector(local, args.streams, min(args.pass_size, B), 1024, 1024)
+        det = StreamedDetector(local, args.streams, pass_size, 1024, 1024)
     else:
-        det = Detector(local, min(args.pass_size, B), 1024, 1024)
+        det = Detector(local, pass_size, 1024, 1024)
     params = Params()
 
     def step():
@@ -83,40 +100,54 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    stage_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         allb = step()
-        stage_ms += det.last_timing()["blur_canny_ms"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # sanity: every rank's boards equal the generator's occupancy
+    # sanity: the boards this rank produced equal the generator's occupancy
     mine = allb[lo:hi]
     ok = bool((mine[:, :361].reshape(-1, 19, 19) == occs).all())
-    timing = det.last_timing()
+    det.close()
+
+    out = None
     if rank == 0:
+        # roofline of the blur+Canny stage: one stream, HIP events around the stage on that stream
+        nr = min(args.roofline_images, B)
+        d1 = Detector(local, min(pass_size, nr), 1024, 1024)
+        d1.detect_device(dev[:nr], params)
+        d1.detect_device(dev[:nr], params)
+        timing = d1.last_timing()
+        d1.close()
+        stage_s = timing["blur_canny_ms"] * 1e-3
+        ach = BLUR_CANNY_BYTES * nr / stage_s / 1e9
+        traffic = measured_traffic()
         images = B * world * args.steps
-        ach = BLUR_CANNY_BYTES * B * args.steps / (stage_ms * 1e-3) / 1e9
         out = {
             "metric": "go-diagram images/sec (1024x1024 greyscale)", "value": images / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU, device-resident, full "
-                                   "hot path incl. board all-gather" % B, "pass_size": det.max_batch, "streams": args.streams,
-                       "boards_match_generator": ok},
-            "roofline": {"bound": "hbm", "kernel": "blur+Canny stage (k_grey, k_median<3,5,7>, k_gauss<3,5,7>, k_sobel_nms_src, k_hysteresis, k_edges_from_map)",
+            "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU (BASELINE configs[2]), "
+                                   "device-resident, full hot path incl. board all-gather" % B,
+                       "pass_size": pass_size, "streams": args.streams, "boards_match_generator": ok},
+            "roofline": {"bound": "hbm",
+                         "kernel": "blur+Canny stage: k_grey, k_median3, k_median57, k_gauss<3,5,7>, k_sobel_nms_planes(main), "
+                                   "k_hysteresis(map 0), k_edges_from_map",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES},
-            "stage_ms_last_step": timing,
+                         "traffic": traffic, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,
+                         "stage_us_per_image": stage_s / nr * 1e6,
+                         "measured_on": "1 stream, %d diagrams, HIP events on the context's stream" % nr},
+            "single_stream_stage_ms": timing,
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_images)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

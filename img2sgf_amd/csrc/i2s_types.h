@@ -51,6 +51,12 @@ struct HoughTrig {        // tables of the three HoughLines calls of find_lines 
     float cos_[3][4];
 };
 
+// two 16-bit lanes per register: arithmetic on these compiles to the packed v_pk_* instructions
+typedef short v2s __attribute__((vector_size(4)));
+__device__ __forceinline__ v2s pk_from(unsigned u) { v2s r; __builtin_memcpy(&r, &u, 4); return r; }
+__device__ __forceinline__ unsigned pk_bits(v2s v) { unsigned u; __builtin_memcpy(&u, &v, 4); return u; }
+__device__ __forceinline__ v2s pk_abs(v2s a) { const v2s n = -a; return a > n ? a : n; }
+
 __device__ __host__ inline int imin(int a, int b) { return a < b ? a : b; }
 __device__ __host__ inline int imax(int a, int b) { return a > b ? a : b; }
 __device__ __host__ inline int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -126,35 +126,49 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     if (tid == 0) s_weak = 0;
     load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, plane, g.pitch, w, h, x0 - 8, y0 - 2, tid);
     __syncthreads();
-    // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry
+    // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry.
+    // Two pixels per register (16-bit lanes, v_pk_* instructions): column sums / row differences of the 3x6
+    // neighbourhood, then dx = col[+1] - col[-1], dy = dif[-1] + 2 dif[0] + dif[+1], mag = |dx| + |dy|.
     constexpr int NSTRIPS = MROWS * MSTRIPS;          // 34 * 18 = 612
     constexpr int PER = (NSTRIPS + 255) / 256;        // 3
-    short gdx[PER][4], gdy[PER][4];
+    v2s gdx01[PER], gdx23[PER], gdy01[PER], gdy23[PER], gm01[PER], gm23[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int i = tid + k * 256;
+        gdx01[k] = gdx23[k] = gdy01[k] = gdy23[k] = gm01[k] = gm23[k] = pk_from(0u);
         if (i < NSTRIPS) {
             const int ry = i / MSTRIPS, s = i - ry * MSTRIPS;
-            int r0[6], r1[6], r2[6];
             const unsigned* p0 = s_src + ry * SSTR + s;
-            unpack6(p0[0], p0[1], p0[2], r0);
-            unpack6(p0[SSTR], p0[SSTR + 1], p0[SSTR + 2], r1);
-            unpack6(p0[2 * SSTR], p0[2 * SSTR + 1], p0[2 * SSTR + 2], r2);
-            int col[6], dif[6];
+            v2s ra[3], rb[3], rc[3];          // pixel pairs (-1,0), (1,2), (3,4) of the three rows
 #pragma unroll
-            for (int j = 0; j < 6; j++) { col[j] = r0[j] + 2 * r1[j] + r2[j]; dif[j] = r2[j] - r0[j]; }
-            const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
-            unsigned m[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int dx = col[q + 2] - col[q], dy = dif[q] + 2 * dif[q + 1] + dif[q + 2];
-                const int gx = gx0 + q;
-                if (gx < 0 || gx >= w || gy < 0 || gy >= h) { dx = 0; dy = 0; }
-                gdx[k][q] = (short)dx; gdy[k][q] = (short)dy;
-                m[q] = (unsigned)(iabs_(dx) + iabs_(dy));
+            for (int j = 0; j < 3; j++) {
+                const unsigned a = p0[j * SSTR], b0 = p0[j * SSTR + 1], c = p0[j * SSTR + 2];
+                ra[j] = pk_from(__builtin_amdgcn_perm(b0, a, 0x0c040c03u));
+                rb[j] = pk_from(__builtin_amdgcn_perm(b0, b0, 0x0c020c01u));
+                rc[j] = pk_from(__builtin_amdgcn_perm(c, b0, 0x0c040c03u));
             }
-            s_mag[ry * MSTR + 2 * s] = m[0] | (m[1] << 16);
-            s_mag[ry * MSTR + 2 * s + 1] = m[2] | (m[3] << 16);
+            const v2s ca = ra[0] + ra[1] + ra[1] + ra[2], cb = rb[0] + rb[1] + rb[1] + rb[2], cc = rc[0] + rc[1] + rc[1] + rc[2];
+            const v2s da = ra[2] - ra[0], db = rb[2] - rb[0], dc = rc[2] - rc[0];
+            v2s dx01 = cb - ca, dx23 = cc - cb;
+            const v2s m01 = pk_from(__builtin_amdgcn_alignbit(pk_bits(db), pk_bits(da), 16));    // (dif0, dif1)
+            const v2s m23 = pk_from(__builtin_amdgcn_alignbit(pk_bits(dc), pk_bits(db), 16));    // (dif2, dif3)
+            v2s dy01 = da + m01 + m01 + db, dy23 = db + m23 + m23 + dc;
+            const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
+            if (gy < 0 || gy >= h || gx0 < 0 || gx0 + 3 >= w) {
+                // strip touches the image border: gradients (hence magnitudes) outside the image are 0
+                const bool row_ok = gy >= 0 && gy < h;
+                unsigned k01 = 0, k23 = 0;
+                if (row_ok && gx0 >= 0 && gx0 < w) k01 |= 0x0000ffffu;
+                if (row_ok && gx0 + 1 >= 0 && gx0 + 1 < w) k01 |= 0xffff0000u;
+                if (row_ok && gx0 + 2 >= 0 && gx0 + 2 < w) k23 |= 0x0000ffffu;
+                if (row_ok && gx0 + 3 >= 0 && gx0 + 3 < w) k23 |= 0xffff0000u;
+                dx01 = pk_from(pk_bits(dx01) & k01); dy01 = pk_from(pk_bits(dy01) & k01);
+                dx23 = pk_from(pk_bits(dx23) & k23); dy23 = pk_from(pk_bits(dy23) & k23);
+            }
+            const v2s mg01 = pk_abs(dx01) + pk_abs(dy01), mg23 = pk_abs(dx23) + pk_abs(dy23);
+            gdx01[k] = dx01; gdx23[k] = dx23; gdy01[k] = dy01; gdy23[k] = dy23; gm01[k] = mg01; gm23[k] = mg23;
+            s_mag[ry * MSTR + 2 * s] = pk_bits(mg01);
+            s_mag[ry * MSTR + 2 * s + 1] = pk_bits(mg23);
         }
     }
     __syncthreads();
@@ -166,37 +180,44 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
         if (ry < 1 || ry > CT_H || s < 1 || s > CT_W / 4) continue;      // apron strips only feed neighbours
         const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
         if (gy >= h || gx0 >= w) continue;
-        // magnitudes of rows ry-1, ry, ry+1 at columns -1 .. 4 of the strip
-        int mg[3][6];
+        unsigned outw = 0x01010101u;
+        const unsigned mb01 = pk_bits(gm01[k]), mb23 = pk_bits(gm23[k]);
+        const int mxall = imax(imax((int)(mb01 & 0xffffu), (int)(mb01 >> 16)), imax((int)(mb23 & 0xffffu), (int)(mb23 >> 16)));
+        if (mxall > low) {
+            // magnitudes of rows ry-1, ry, ry+1 at columns -1 .. 4 of the strip
+            int mg[3][6];
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++) {
-            const unsigned* pm = s_mag + (ry - 1 + rr) * MSTR + 2 * s;
-            const unsigned a = pm[-1], b0 = pm[0], b1 = pm[1], c = pm[2];
-            mg[rr][0] = (int)(a >> 16); mg[rr][1] = (int)(b0 & 0xffffu); mg[rr][2] = (int)(b0 >> 16);
-            mg[rr][3] = (int)(b1 & 0xffffu); mg[rr][4] = (int)(b1 >> 16); mg[rr][5] = (int)(c & 0xffffu);
-        }
-        unsigned outw = 0;
+            for (int rr = 0; rr < 3; rr++) {
+                const unsigned* pm = s_mag + (ry - 1 + rr) * MSTR + 2 * s;
+                const unsigned a = pm[-1], b0 = pm[0], b1 = pm[1], c = pm[2];
+                mg[rr][0] = (int)(a >> 16); mg[rr][1] = (int)(b0 & 0xffffu); mg[rr][2] = (int)(b0 >> 16);
+                mg[rr][3] = (int)(b1 & 0xffffu); mg[rr][4] = (int)(b1 >> 16); mg[rr][5] = (int)(c & 0xffffu);
+            }
+            outw = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            // branch-free NMS: evaluate the three sector rules and select (divergent branches cost more than the ALU work)
-            const int mcur = mg[1][q + 1];
-            const int xs = gdx[k][q], ys = gdy[k][q];
-            const int ax = iabs_(xs), ay = iabs_(ys) << 15;
-            const int tg22x = ax * 13573;
-            const int tg67x = tg22x + (ax << 16);
-            const int c_h = (mcur > mg[1][q]) & (mcur >= mg[1][q + 2]);
-            const int c_v = (mcur > mg[0][q + 1]) & (mcur >= mg[2][q + 1]);
-            // diagonal: s = ((xs ^ ys) < 0) ? -1 : 1 -> compare (row-1, x-s) and (row+1, x+s).  The selection is done with a
-            // bit mask on VALUES (a ?: on array elements gets folded into a dynamic register-array index = an 18-way
-            // select chain).
-            const int msk = (xs ^ ys) >> 31;                // all ones when the signs differ
-            const int ul = mg[0][q], ur = mg[0][q + 2], dl = mg[2][q], dr = mg[2][q + 2];
-            const int d_a = ul ^ ((ul ^ ur) & msk);
-            const int d_b = dr ^ ((dr ^ dl) & msk);
-            const int c_d = (mcur > d_a) & (mcur > d_b);
-            const int keep = (ay < tg22x) ? c_h : ((ay > tg67x) ? c_v : c_d);
-            const unsigned o = ((mcur > low) & keep) ? ((mcur > high) ? 2u : 0u) : 1u;
-            outw |= o << (8 * q);
+            for (int q = 0; q < 4; q++) {
+                // branch-free NMS: evaluate the three sector rules and select (divergent branches cost more than the ALU work)
+                const int mcur = mg[1][q + 1];
+                const unsigned xb = pk_bits(q < 2 ? gdx01[k] : gdx23[k]), yb = pk_bits(q < 2 ? gdy01[k] : gdy23[k]);
+                const int xs = (q & 1) ? ((int)xb >> 16) : (int)(short)(xb & 0xffffu);
+                const int ys = (q & 1) ? ((int)yb >> 16) : (int)(short)(yb & 0xffffu);
+                const int ax = iabs_(xs), ay = iabs_(ys) << 15;
+                const int tg22x = ax * 13573;
+                const int tg67x = tg22x + (ax << 16);
+                const int c_h = (mcur > mg[1][q]) & (mcur >= mg[1][q + 2]);
+                const int c_v = (mcur > mg[0][q + 1]) & (mcur >= mg[2][q + 1]);
+                // diagonal: s = ((xs ^ ys) < 0) ? -1 : 1 -> compare (row-1, x-s) and (row+1, x+s).  The selection is done with a
+                // bit mask on VALUES (a ?: on array elements gets folded into a dynamic register-array index = an 18-way
+                // select chain).
+                const int msk = (xs ^ ys) >> 31;                // all ones when the signs differ
+                const int ul = mg[0][q], ur = mg[0][q + 2], dl = mg[2][q], dr = mg[2][q + 2];
+                const int d_a = ul ^ ((ul ^ ur) & msk);
+                const int d_b = dr ^ ((dr ^ dl) & msk);
+                const int c_d = (mcur > d_a) & (mcur > d_b);
+                const int keep = (ay < tg22x) ? c_h : ((ay > tg67x) ? c_v : c_d);
+                const unsigned o = ((mcur > low) & keep) ? ((mcur > high) ? 2u : 0u) : 1u;
+                outw |= o << (8 * q);
+            }
         }
         uint8_t* dstp = mp + (size_t)gy * g.pitch + gx0;
         bool wk;

@@ -99,3 +99,52 @@ def synth_batch(seeds, noisy=False, geom=GEOM_1024):
     for n, s in enumerate(seeds):
         imgs[n], occs[n] = synth_diagram(int(s), noisy, geom)
     return imgs, occs
+
+
+# ---- batched rendering (torch, CPU or GPU) --------------------------------------------------------------------------
+# In GEOM_1024 a stone (47 px) is narrower than the grid pitch (50 px), so the diagram is a 19 x 19 mosaic of 50 x 50
+# cells whose content depends only on the cell position and its occupancy.  The cell library is cut out of three
+# images rendered by synth_diagram() (all empty / all black / all white), so the mosaic is bit-identical to it.
+_CELL_LIB = None
+
+
+def _cell_library():
+    global _CELL_LIB
+    if _CELL_LIB is None:
+        g = GEOM_1024
+        lib = np.empty((3, N, N, g.pitch, g.pitch), np.uint8)          # [occ][col i][row j][y][x]
+        for occ in range(3):
+            img = _render(np.full((N, N), occ, np.uint8), g)
+            for i in range(N):
+                for j in range(N):
+                    x0, y0 = g.origin_x + g.pitch * i - g.pitch // 2, g.origin_y + g.pitch * j - g.pitch // 2
+                    lib[occ, i, j] = img[y0:y0 + g.pitch, x0:x0 + g.pitch]
+        _CELL_LIB = lib
+    return _CELL_LIB
+
+
+def _render(occ, g):
+    """synth_diagram's drawing with a given occupancy matrix."""
+    saved = occupancy
+    try:
+        globals()["occupancy"] = lambda seed, nx=19, ny=19: occ
+        return synth_diagram(0, False, g)[0]
+    finally:
+        globals()["occupancy"] = saved
+
+
+def synth_batch_torch(seeds, device="cpu"):
+    """(B,1024,1024) uint8 torch tensor on `device` and the (B,19,19) numpy occupancies; equals synth_batch(seeds)."""
+    import torch
+    g = GEOM_1024
+    occs = np.stack([occupancy(int(s)) for s in seeds]) if len(seeds) else np.zeros((0, N, N), np.uint8)
+    lib = torch.from_numpy(_cell_library()).to(device)                   # (3,19,19,50,50)
+    o = torch.from_numpy(occs.astype(np.int64)).to(device)               # (B,19,19) [col i][row j]
+    ii = torch.arange(N, device=device).view(1, N, 1).expand_as(o)
+    jj = torch.arange(N, device=device).view(1, 1, N).expand_as(o)
+    cells = lib[o, ii, jj]                                               # (B, i, j, y, x)
+    mosaic = cells.permute(0, 2, 3, 1, 4).reshape(len(seeds), N * g.pitch, N * g.pitch)   # (B, j*50+y, i*50+x)
+    out = torch.full((len(seeds), g.height, g.width), 255, dtype=torch.uint8, device=device)
+    x0, y0 = g.origin_x - g.pitch // 2, g.origin_y - g.pitch // 2
+    out[:, y0:y0 + N * g.pitch, x0:x0 + N * g.pitch] = mosaic
+    return out, occs

@@ -107,6 +107,27 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi:lo} (0-3 = lo, 4-7 = hi), 0x0c = 0x00
+static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel)
+{
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned s = (sel >> (8 * i)) & 0xff;
+        unsigned b = 0;
+        if (s < 8) b = (unsigned)(v >> (8 * s)) & 0xff;
+        else if (s == 0x0c) b = 0;
+        else if (s >= 0x0d) b = 0xff;
+        else { fprintf(stderr, "hipemu: unsupported v_perm selector %#x\n", s); abort(); }
+        r |= b << (8 * i);
+    }
+    return r;
+}
+// v_alignbit_b32: ({hi:lo} >> shift) & 0xffffffff
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned shift)
+{
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (shift & 31));
+}
 static inline int __mul24(int a, int b) { return a * b; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }

@@ -51,7 +51,7 @@ def test_tiny_images(lib):
     det = Detector(0, 4, 70, 70, lib=lib)
     rng = np.random.default_rng(5)
     imgs = [rng.integers(0, 256, (h, w), dtype=np.uint8) for (h, w) in [(1, 1), (2, 5), (7, 3), (33, 65)]]
-    parity.run_and_compare(det, imgs)
+    parity.run_and_compare(det, imgs, internals=True)
     det.close()
 
 

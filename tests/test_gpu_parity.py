@@ -34,11 +34,14 @@ def test_small_synthetic_with_internals():
 
 
 def test_tiny_and_ragged():
-    det = Detector(0, 3, 330, 300)
+    det = Detector(0, 8, 330, 300)      # one device pass, so every image's planes are still resident for the comparison
     rng = np.random.default_rng(5)
     a = synth.synth_diagram(2, geom=synth.GEOM_SMALL)[0]
     imgs = [rng.integers(0, 256, (h, w), dtype=np.uint8) for (h, w) in [(1, 1), (2, 5), (7, 3), (33, 65), (130, 129)]]
     imgs += [a, np.ascontiguousarray(a[:200, :250]), np.pad(a, ((10, 30), (5, 40)), constant_values=255)]
+    parity.run_and_compare(det, imgs, internals=True)
+    det.close()
+    det = Detector(0, 3, 330, 300)      # and the same images through three passes
     parity.run_and_compare(det, imgs)
     det.close()
 
