@@ -264,16 +264,18 @@ static GridParams grid_params(const i2s_params* p)
     return gp;
 }
 
-static int run_hysteresis(i2s_ctx* ctx, int phase, int m_first, int nmaps, dim3 tiles)
+static int run_hysteresis(i2s_ctx* ctx, int phase, int m_first, int nmaps, int gx, int gy)
 {
     int* flags = ctx->d_flags + (size_t)phase * HYST_MAX_PASSES;
-    dim3 grid(tiles.x, tiles.y, ctx->geo.nb * nmaps);
+    const dim3 grid((unsigned)gx * gy * ctx->geo.nb * nmaps);
     for (int pass = 0; pass < ctx->hyst_passes; pass++)
         hipLaunchKernelGGL(k_hysteresis, grid, dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, plane_ptr(ctx, I2S_PLANE_CANNY_MAP),
-                           m_first, flags, pass, ctx->d_weak, ctx->d_chg);
+                           m_first, flags, pass, ctx->d_weak, ctx->d_chg, gx, gy);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], flags + ctx->hyst_passes - 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // One device pass over nb images whose descriptors are already in h_desc.
 static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool has_c3, const i2s_params* p,
@@ -302,56 +304,47 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
         uint8_t* map0 = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
         const dim3 b64x4(64, 4), b256(256);
-        const dim3 g_row((wmax + 255) / 256, (hmax + 3) / 4, nb);
-        const dim3 g_f((wmax + FT_W - 1) / FT_W, (hmax + FT_H - 1) / FT_H, nb);
-        const dim3 g_h(g_f.x, g_f.y, 1);
+        // tile grids of this pass (1-D launches, XCD-aware tile order inside the kernels)
+        const int rx = cdiv(wmax, 256), ry = cdiv(hmax, 4);            // row kernels: 256 x 4 pixels per workgroup
+        const int fx = cdiv(wmax, FT_W), fy = cdiv(hmax, FT_H);        // 64 x 32 tiles
+        const int mx = cdiv(wmax, MT_W), my = cdiv(hmax, MT_H);        // 56 x 72 tiles
+        const int ebx = cdiv(wmax, 4 * EB), eby = cdiv(hmax, EB);      // 128 x 32 (4 edge bins)
+        const int vx = cdiv(wmax, VT), vy = cdiv(hmax, VT);            // 126 x 126 accumulator cells
+        const dim3 g_row((unsigned)rx * ry * nb), g_f((unsigned)fx * fy * nb), g_m((unsigned)mx * my * nb);
 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
-        hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift);
-        hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3));
-        {
-            const dim3 g_m((wmax + MT_W - 1) / MT_W, (hmax + MT_H - 1) / MT_H, nb);
-            hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
-                               plane_ptr(ctx, I2S_PLANE_MEDIAN7));
-        }
-        hipLaunchKernelGGL((k_gauss<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3), t3);
-        hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5);
-        hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7);
-        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, g_f, b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, ctx->d_weak);
-        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, ctx->d_weak);
-        rc = run_hysteresis(ctx, 0, 0, 1, g_h);
+        hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
+        hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
+        hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+                           plane_ptr(ctx, I2S_PLANE_MEDIAN7), mx, my);
+        hipLaunchKernelGGL((k_gauss<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3), t3, fx, fy);
+        hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5, fx, fy);
+        hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7, fx, fy);
+        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, g_f, b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, ctx->d_weak, fx, fy);
+        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, ctx->d_weak, fx, fy);
+        rc = run_hysteresis(ctx, 0, 0, 1, fx, fy);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES));
+        hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES), rx, ry);
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
-        {
-            const dim3 g_v(g_f.x, g_f.y, nb * NVAR);
-            hipLaunchKernelGGL(k_sobel_nms_planes, g_v, b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo, p->hc_param1, 0, ctx->d_weak);
-        }
-        rc = run_hysteresis(ctx, 1, 1, NVAR, g_h);
+        hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)fx * fy * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo,
+                           p->hc_param1, 0, ctx->d_weak, fx, fy);
+        rc = run_hysteresis(ctx, 1, 1, NVAR, fx, fy);
         if (rc) return rc;
-
-        {
-            const dim3 g_vote((wmax + VT - 1) / VT, (hmax + VT - 1) / VT, nb * NVAR);
-            const dim3 g_bins((wmax + 4 * EB - 1) / (4 * EB), (hmax + EB - 1) / EB, nb * NVAR);
-            hipLaunchKernelGGL(k_edge_bins, g_bins, b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
-                               ctx->d_bin_ent, ctx->d_bin_cnt);
-            hipLaunchKernelGGL(k_vote_centres, g_vote, dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
-                               p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
-                               ctx->debug ? ctx->d_dbg_acc : (int*)nullptr);
-            hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
-                               ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
-                               ctx->d_est_keys, est_count(ctx));
-            hipLaunchKernelGGL(k_circles_final, dim3(nb * NVAR), b256, 0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx),
-                               p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
-        }
+        hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
+                           ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
+        hipLaunchKernelGGL(k_vote_centres, dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
+                           ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                           ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+        hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
+                           ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
+                           ctx->d_est_keys, est_count(ctx));
+        hipLaunchKernelGGL(k_circles_final, dim3(nb * NVAR), b256, 0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx),
+                           p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));
 
         hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res);
-        {
-            const dim3 g_e((wmax + ET_W - 1) / ET_W, (hmax + ET_H - 1) / ET_H, nb);
-            hipLaunchKernelGGL(k_erase_lines, g_e, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
-                               plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow);
-        }
+        hipLaunchKernelGGL(k_erase_lines, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
+                           plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, fx, fy);
         hipLaunchKernelGGL(k_line_peaks, dim3(nb), b256, 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
 

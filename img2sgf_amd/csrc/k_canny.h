@@ -15,7 +15,8 @@ constexpr int CT_H = 32;
 // Sobel + NMS of one tile.  src(y,x,c) = sp[y*sstride + x*CN + c].
 template <int CN>
 __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, int sstride, int w, int h,
-                                               int low, int high, uint8_t* __restrict__ mp, int mpitch, int* __restrict__ weak_flag)
+                                               int low, int high, uint8_t* __restrict__ mp, int mpitch, int* __restrict__ weak_flag,
+                                               int tile_x, int tile_y)
 {
     __shared__ int s_weak;
     constexpr int SW = CT_W + 4, SH = CT_H + 4;   // source tile with 2-px apron
@@ -23,7 +24,7 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
     __shared__ uint8_t s_src[SH][SW * CN + 4];
     __shared__ short s_dx[MH][MW], s_dy[MH][MW];
     __shared__ unsigned short s_mag[MH][MW];
-    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int x0 = tile_x * CT_W, y0 = tile_y * CT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     if (tid == 0) s_weak = 0;
@@ -90,13 +91,14 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
 // Main Canny (map 0) on the source image: grid (tiles_x, tiles_y, nb).
 template <int CN>
 __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ map0,
-                                                       int low, int high, int* __restrict__ weak)
+                                                       int low, int high, int* __restrict__ weak, int gx, int gy)
 {
-    const int b = blockIdx.z;
+    const TileId t = tile_of_block(gx, gy);
+    const int b = t.z;
     const ImgDesc im = desc[b];
     if (im.cn != CN) return;
     sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, g.pitch,
-                       weak + (size_t)b * g.tiles + (size_t)blockIdx.y * g.tw + blockIdx.x);
+                       weak + (size_t)b * g.tiles + (size_t)t.ty * g.tw + t.tx, t.tx, t.ty);
 }
 
 // Sobel + NMS on single-channel PLANES, 4 pixels per thread with dword LDS traffic.
@@ -107,18 +109,19 @@ __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict
 // planes = variant plane 0 base, maps = map 0 base.
 __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
                                                           uint8_t* __restrict__ maps, int v_first, int low, int high, int main_mode,
-                                                          int* __restrict__ weak)
+                                                          int* __restrict__ weak, int gx, int gy)
 {
     __shared__ int s_weak;
     constexpr int SROWS = CT_H + 4, SWORDS = CT_W / 4 + 4, SSTR = SWORDS + 1;   // source rows y0-2.., x0-8 .. x0+72
     constexpr int MROWS = CT_H + 2, MSTRIPS = CT_W / 4 + 2, MSTR = 2 * MSTRIPS + 1;   // mag rows y0-1.., x0-4 .. x0+68 (u16 pairs)
     __shared__ unsigned s_src[SROWS * SSTR];
     __shared__ unsigned s_mag[MROWS * MSTR];
-    const int b = blockIdx.z % g.nb;
-    const int v = main_mode ? 0 : v_first + blockIdx.z / g.nb;
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z % g.nb;
+    const int v = main_mode ? 0 : v_first + tl.z / g.nb;
     if (main_mode && desc[b].cn != 1) return;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int x0 = tl.tx * CT_W, y0 = tl.ty * CT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const uint8_t* plane = planes + ((size_t)v * g.nb + b) * g.slot;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
         if (wk) s_weak = 1;
     }
     __syncthreads();
-    if (tid == 0) weak[((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)blockIdx.y * g.tw + blockIdx.x] = s_weak;
+    if (tid == 0) weak[((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tl.tx] = s_weak;
 }
 
 // One hysteresis pass over maps [m_first, m_first + gridDim.z / nb).  Each block brings its 64x32 tile (with a read-only
@@ -243,26 +246,27 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
 // maps points at map 0; map m of image b at (m * nb + b) * slot.  grid (tiles_x, tiles_y, nb * nmaps), block 256.
 __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
                                                     int m_first, int* __restrict__ flags, int pass,
-                                                    const int* __restrict__ weak, int* __restrict__ chg)
+                                                    const int* __restrict__ weak, int* __restrict__ chg, int gx, int gy)
 {
     constexpr int SROWS = CT_H + 2, SWORDS = CT_W / 4 + 2, SSTR = SWORDS + 1;    // bytes x0-4 .. x0+68, rows y0-1 .. y0+32
     __shared__ unsigned s_w[SROWS * SSTR];
     __shared__ int s_flag[2];
     if (pass > 0 && flags[pass - 1] == 0) return;
-    const int b = blockIdx.z % g.nb;
-    const int m = m_first + blockIdx.z / g.nb;
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z % g.nb;
+    const int m = m_first + tl.z / g.nb;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int x0 = tl.tx * CT_W, y0 = tl.ty * CT_H;
     if (x0 >= w || y0 >= h) return;
     const size_t tbase = ((size_t)m * g.nb + b) * g.tiles;
-    const int tile = blockIdx.y * g.tw + blockIdx.x;
+    const int tile = tl.ty * g.tw + tl.tx;
     if (weak[tbase + tile] == 0) return;
     if (pass > 0) {
         const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
         bool any = false;
         for (int dy = -1; dy <= 1; dy++)
             for (int dx = -1; dx <= 1; dx++) {
-                const int tx = (int)blockIdx.x + dx, ty = (int)blockIdx.y + dy;
+                const int tx = tl.tx + dx, ty = tl.ty + dy;
                 if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty && chg[tbase + ty * g.tw + tx] == pass) any = true;
             }
         if (!any) return;
@@ -313,12 +317,13 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
 
 // edges = 255 where map0 == 2 else 0 (img2sgf.py:162 output; also variant plane 1 and the erase target).
 __global__ __launch_bounds__(256) void k_edges_from_map(const ImgDesc* __restrict__ desc, Geo g,
-                                                        const uint8_t* __restrict__ map0, uint8_t* __restrict__ edges)
+                                                        const uint8_t* __restrict__ map0, uint8_t* __restrict__ edges, int gx, int gy)
 {
-    const int b = blockIdx.z;
+    const TileId t = tile_of_block(gx, gy);
+    const int b = t.z;
     const int w = desc[b].w, h = desc[b].h;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = t.ty * 4 + threadIdx.y;
+    const int x0 = (t.tx * 64 + threadIdx.x) * 4;
     if (y >= h || x0 >= w) return;
     const uint8_t* mp = map0 + (size_t)b * g.slot + (size_t)y * g.pitch;
     uint8_t* e = edges + (size_t)b * g.slot + (size_t)y * g.pitch;

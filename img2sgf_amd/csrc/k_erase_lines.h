@@ -53,16 +53,17 @@ __global__ __launch_bounds__(256) void k_concat_circles(Geo g, const float* __re
 __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__ desc, Geo g,
                                                      const uint8_t* __restrict__ edges, uint8_t* __restrict__ removed,
                                                      const i2s_result* __restrict__ res, HoughTrig trig,
-                                                     int* __restrict__ lacc, int lrow)
+                                                     int* __restrict__ lacc, int lrow, int gx, int gy)
 {
     __shared__ short s_box[256][4];
     __shared__ int s_idx[256];
     __shared__ int s_n;
     __shared__ int s_hist[LROWS][LB];
     __shared__ int s_rmin[LROWS];
-    const int b = blockIdx.z;
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * ET_W, y0 = blockIdx.y * ET_H;
+    const int x0 = tl.tx * ET_W, y0 = tl.ty * ET_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const i2s_result* R = res + b;

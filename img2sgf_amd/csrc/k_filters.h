@@ -15,12 +15,13 @@ constexpr int FT_H = 32;
 // ---- K1: grey plane.  cn==1: copy; cn==3: (ch0*B + ch1*G + ch2*R + half) >> shift, where the
 // reference hands RGB data to COLOR_BGR2GRAY, so ch0 (=R) is weighted as "blue" (img2sgf.py:153).
 // block (64,4), each thread 4 pixels.
-__global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ grey, int shift)
+__global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ grey, int shift, int gx, int gy)
 {
-    const int b = blockIdx.z;
+    const TileId t = tile_of_block(gx, gy);
+    const int b = t.z;
     const ImgDesc im = desc[b];
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = t.ty * 4 + threadIdx.y;
+    const int x0 = (t.tx * 64 + threadIdx.x) * 4;
     if (y >= im.h || x0 >= im.w) return;
     const uint8_t* s = im.src + (size_t)y * im.sstride;
     uint8_t* o = grey + (size_t)b * g.slot + (size_t)y * g.pitch;
@@ -38,16 +39,17 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
 // horizontal: t = sum w_i * p (<= 65280, 16 bit); vertical: a = sum w_j * t (32 bit); out = (a + 32768) >> 16.
 template <int K>
 __global__ __launch_bounds__(256) void k_gauss(const ImgDesc* __restrict__ desc, Geo g,
-                                               const uint8_t* __restrict__ grey, uint8_t* __restrict__ out, Taps taps)
+                                               const uint8_t* __restrict__ grey, uint8_t* __restrict__ out, Taps taps, int gx, int gy)
 {
     constexpr int R = K / 2;
     constexpr int SROWS = FT_H + 2 * R, SWORDS = FT_W / 4 + 2, SSTR = SWORDS + 1;   // bytes x0-4 .. x0+68
     constexpr int NS = FT_W / 4, HSTR = 2 * NS + 1;                                 // u16 pairs per row
     __shared__ unsigned s_src[SROWS * SSTR];
     __shared__ unsigned s_h[SROWS * HSTR];
-    const int b = blockIdx.z;
+    const TileId t = tile_of_block(gx, gy);
+    const int b = t.z;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int x0 = t.tx * FT_W, y0 = t.ty * FT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_R101>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - R, tid);
@@ -102,14 +104,15 @@ __device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, 
 // column), then median = med3( max of the column minima, med of the column medians, min of the column maxima ).
 // 4 pixels per thread, dword LDS traffic.
 __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ desc, Geo g,
-                                                 const uint8_t* __restrict__ grey, uint8_t* __restrict__ out)
+                                                 const uint8_t* __restrict__ grey, uint8_t* __restrict__ out, int gx, int gy)
 {
     constexpr int SROWS = FT_H + 2, SWORDS = FT_W / 4 + 2, SSTR = SWORDS + 1;
     constexpr int NS = FT_W / 4;
     __shared__ unsigned s_src[SROWS * SSTR];
-    const int b = blockIdx.z;
+    const TileId t = tile_of_block(gx, gy);
+    const int b = t.z;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int x0 = t.tx * FT_W, y0 = t.ty * FT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - 1, tid);
@@ -181,13 +184,14 @@ __device__ __forceinline__ unsigned median_planes(const unsigned (&plo)[8], cons
 }
 
 __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
-                                                  uint8_t* __restrict__ out5, uint8_t* __restrict__ out7)
+                                                  uint8_t* __restrict__ out5, uint8_t* __restrict__ out7, int gx, int gy)
 {
     __shared__ unsigned s_src[M_ROWS * M_SSTR];
     __shared__ unsigned long long s_pl[8 * M_ROWS];
-    const int b = blockIdx.z;
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * MT_W, y0 = blockIdx.y * MT_H;
+    const int x0 = tl.tx * MT_W, y0 = tl.ty * MT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - 3, tid);

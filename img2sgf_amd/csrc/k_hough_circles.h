@@ -42,7 +42,7 @@ __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitc
 // bin_cnt[(bv * g.bins) + by * g.bw + bx], bin_ent[... * EB_CAP + k].
 __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ desc, Geo g,
                                                    const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
-                                                   uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt)
+                                                   uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt, int gx, int gy)
 {
     // one block = 4 horizontally adjacent bins (128 x 32 pixels); one 16-byte map load per thread.  Edge positions are
     // first compacted into an LDS list so that the gradient work (8 neighbour loads, sqrt, 2 divides) is spread evenly
@@ -50,15 +50,16 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     __shared__ unsigned s_list[4 * EB * EB];
     __shared__ int s_nl;
     __shared__ int s_n[4];
-    const int b = blockIdx.z / NVAR, v = blockIdx.z % NVAR;
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z / NVAR, v = tl.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = blockIdx.x * (4 * EB), y0 = blockIdx.y * EB;
+    const int x0 = tl.tx * (4 * EB), y0 = tl.ty * EB;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const size_t off = ((size_t)v * g.nb + b) * g.slot;
     const uint8_t* plane = planes + off;
     const uint8_t* map = maps + off;
-    const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)blockIdx.y * g.bw + (size_t)blockIdx.x * 4;
+    const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)tl.ty * g.bw + (size_t)tl.tx * 4;
     if (tid < 4) s_n[tid] = 0;
     if (tid == 4) s_nl = 0;
     __syncthreads();
@@ -120,12 +121,13 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
                                                       const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
                                                       int min_r, int max_r, int acc_thr,
                                                       unsigned* __restrict__ cent_list, int* __restrict__ cent_count,
-                                                      int* __restrict__ dbg_acc)
+                                                      int* __restrict__ dbg_acc, int gx, int gy)
 {
     __shared__ unsigned s_acc[(VL / 2) * VASTR];
-    const int b = blockIdx.z / NVAR, v = blockIdx.z % NVAR;
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z / NVAR, v = tl.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
-    const int cx0 = blockIdx.x * VT, cy0 = blockIdx.y * VT;    // first interior cell
+    const int cx0 = tl.tx * VT, cy0 = tl.ty * VT;    // first interior cell
     if (cx0 >= w || cy0 >= h) return;
     const int tid = threadIdx.x;
     const int bv = b * NVAR + v;
