@@ -39,6 +39,8 @@ struct i2s_ctx {
     int* d_counts = nullptr;     // cent_count | est_count | vcount | overflow
     unsigned long long* d_est_keys = nullptr;
     float* d_vcirc = nullptr;
+    int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
+    unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
     int* d_weak = nullptr;       // [NMAP][nb][tiles] tile holds weak pixels
     int* d_chg = nullptr;        // [NMAP][nb][tiles] last hysteresis pass (+1) that changed the tile
     uint2* d_bin_ent = nullptr;
@@ -115,7 +117,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -142,6 +144,8 @@ static int create_impl(i2s_ctx* ctx)
     g.tw = (ctx->max_w + CT_W - 1) / CT_W;
     g.tiles = g.tw * ((ctx->max_h + CT_H - 1) / CT_H);
     const size_t nb = ctx->max_batch;
+    I2S_HIP(hipMalloc(&ctx->d_tl_cnt, nb * g.tiles * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(unsigned short)));
     I2S_HIP(hipMalloc(&ctx->d_weak, nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_chg, nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
@@ -342,9 +346,10 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                            p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));
 
-        hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res);
+        hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, ctx->d_desc, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res,
+                           ctx->d_tl_cnt, ctx->d_tl_idx);
         hipLaunchKernelGGL(k_erase_lines, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
-                           plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, fx, fy);
+                           plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, fx, fy, ctx->d_tl_cnt, ctx->d_tl_idx);
         hipLaunchKernelGGL(k_line_peaks, dim3(nb), b256, 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
 

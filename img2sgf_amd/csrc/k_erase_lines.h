@@ -11,14 +11,21 @@ constexpr int LB = 128;          // LDS histogram bins per (call, angle) per til
 constexpr int LANG = 4;          // angle rows reserved per HoughLines call
 constexpr int LROWS = 3 * LANG;  // accumulator rows per image
 
-// Concatenate the per-variant circle lists into the reference's `circles` array order
-// (slots of the blur bank, img2sgf.py:171-186).  grid (nb), block 256.
-__global__ __launch_bounds__(256) void k_concat_circles(Geo g, const float* __restrict__ vcirc, const int* __restrict__ vcount,
-                                                        const int* __restrict__ overflow, i2s_result* __restrict__ res)
+constexpr int TL_CAP = 64;       // circles listed per 64x32 tile; a tile touched by more falls back to scanning all circles
+
+// Concatenate the per-variant circle lists into the reference's `circles` array order (slots of the blur bank,
+// img2sgf.py:171-186) and bin the circles' erase boxes by 64x32 tile: tl_cnt[b * g.tiles + tile] (may exceed TL_CAP =
+// overflow marker), tl_idx[(b * g.tiles + tile) * TL_CAP + k] = circle index.  grid (nb), block 256.
+__global__ __launch_bounds__(256) void k_concat_circles(const ImgDesc* __restrict__ desc, Geo g, const float* __restrict__ vcirc,
+                                                        const int* __restrict__ vcount, const int* __restrict__ overflow,
+                                                        i2s_result* __restrict__ res, int* __restrict__ tl_cnt, unsigned short* __restrict__ tl_idx)
 {
     __shared__ int s_off[NSLOT + 1];
     const int b = blockIdx.x;
     i2s_result* R = res + b;
+    const int w = desc[b].w, h = desc[b].h;
+    const int ntx = (w + ET_W - 1) / ET_W, nty = (h + ET_H - 1) / ET_H;
+    for (int t = threadIdx.x; t < ntx * nty; t += 256) tl_cnt[(size_t)b * g.tiles + (t / ntx) * g.tw + (t % ntx)] = 0;
     if (threadIdx.x == 0) {
         int o = 0;
         for (int s = 0; s < NSLOT; s++) {
@@ -40,6 +47,21 @@ __global__ __launch_bounds__(256) void k_concat_circles(Geo g, const float* __re
         const float* src = vcirc + (size_t)(b * NVAR + slot_variant(s)) * VCIRC_CAP * 3;
         float* dst = &R->circles[s_off[s]][0];
         for (int i = threadIdx.x; i < n * 3; i += 256) dst[i] = src[i];
+        // erase box of circle (s_off[s] + i): r + 2 in float32, corners rounded half-to-even (img2sgf.py:193-195)
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float xc = src[3 * i], yc = src[3 * i + 1], r = src[3 * i + 2] + 2.0f;
+            const int bx0 = __float2int_rn(xc - r), by0 = __float2int_rn(yc - r);
+            const int bx1 = __float2int_rn(xc + r), by1 = __float2int_rn(yc + r);
+            const int lo_x = imax(imin(bx0, bx1), 0), hi_x = imin(imax(bx0, bx1), w - 1);
+            const int lo_y = imax(imin(by0, by1), 0), hi_y = imin(imax(by0, by1), h - 1);
+            if (lo_x > hi_x || lo_y > hi_y) continue;
+            for (int ty = lo_y / ET_H; ty <= hi_y / ET_H; ty++)
+                for (int tx = lo_x / ET_W; tx <= hi_x / ET_W; tx++) {
+                    const size_t t = (size_t)b * g.tiles + (size_t)ty * g.tw + tx;
+                    const int k = atomicAdd(&tl_cnt[t], 1);
+                    if (k < TL_CAP) tl_idx[t * TL_CAP + k] = (unsigned short)(s_off[s] + i);
+                }
+        }
     }
 }
 
@@ -53,7 +75,8 @@ __global__ __launch_bounds__(256) void k_concat_circles(Geo g, const float* __re
 __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__ desc, Geo g,
                                                      const uint8_t* __restrict__ edges, uint8_t* __restrict__ removed,
                                                      const i2s_result* __restrict__ res, HoughTrig trig,
-                                                     int* __restrict__ lacc, int lrow, int gx, int gy)
+                                                     int* __restrict__ lacc, int lrow, int gx, int gy,
+                                                     const int* __restrict__ tl_cnt, const unsigned short* __restrict__ tl_idx)
 {
     __shared__ short s_box[256][4];
     __shared__ int s_idx[256];
@@ -86,11 +109,17 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     int best[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) best[k] = -1;
-    for (int base = 0; base < nc; base += 256) {
+    // circles whose erase box touches this tile: the per-tile list built by k_concat_circles (order irrelevant: the
+    // largest index wins), or every circle of the image when that list overflowed
+    const size_t tslot = (size_t)b * g.tiles + (size_t)tl.ty * g.tw + tl.tx;
+    const int tcnt = nc > 0 ? tl_cnt[tslot] : 0;
+    const bool listed = tcnt <= TL_CAP;
+    const int ncand = listed ? tcnt : nc;
+    for (int base = 0; base < ncand; base += 256) {
         if (tid == 0) s_n = 0;
         __syncthreads();
-        const int i = base + tid;
-        if (i < nc) {
+        if (base + tid < ncand) {
+            const int i = listed ? (int)tl_idx[tslot * TL_CAP + base + tid] : base + tid;
             const float xc = R->circles[i][0], yc = R->circles[i][1];
             const float r = R->circles[i][2] + 2.0f;
             const int bx0 = __float2int_rn(xc - r), by0 = __float2int_rn(yc - r);
@@ -105,18 +134,20 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         }
         __syncthreads();
         const int n = s_n;
+        if (n > 0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int p = tid + k * 256;
-            const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
-            int bst = best[k];
-            for (int j = 0; j < n; j++)
-                if (px >= s_box[j][0] && px <= s_box[j][1] && py >= s_box[j][2] && py <= s_box[j][3]) bst = imax(bst, s_idx[j]);
-            best[k] = bst;
+            for (int k = 0; k < 8; k++) {
+                const int p = tid + k * 256;
+                const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
+                int bst = best[k];
+                for (int j = 0; j < n; j++)
+                    if (px >= s_box[j][0] && px <= s_box[j][1] && py >= s_box[j][2] && py <= s_box[j][3]) bst = imax(bst, s_idx[j]);
+                best[k] = bst;
+            }
         }
         __syncthreads();
     }
-    if (nc == 0) __syncthreads();   // s_hist / s_rmin initialisation
+    if (ncand == 0) __syncthreads();   // s_hist / s_rmin initialisation
     const uint8_t* e = edges + (size_t)b * g.slot;
     uint8_t* o = removed + (size_t)b * g.slot;
 #pragma unroll

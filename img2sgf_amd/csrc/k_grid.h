@@ -123,8 +123,11 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
 {
     __shared__ float s_sorted[I2S_MAX_LINES];
     __shared__ double s_tmp[2][I2S_MAX_CENTRES + 4];
+    __shared__ double s_cen[2][I2S_MAX_CENTRES];      // hcentres / vcentres
+    __shared__ double s_cmp[2][I2S_MAX_CENTRES];      // hcentres_complete / vcentres_complete (global memory is only written)
     __shared__ int s_win[I2S_BOARD_SIZE * I2S_BOARD_SIZE][4];
     __shared__ unsigned char s_det[I2S_BOARD_SIZE][I2S_BOARD_SIZE];
+    __shared__ double s_br[I2S_BOARD_SIZE * I2S_BOARD_SIZE];
     __shared__ int s_i[8];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -144,8 +147,8 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
         return;
     }
     if (do_cluster) {
-        cluster_axis(R->hlines, R->n_hlines, s_sorted, gp.min_grid_spacing, R->hcentres, &s_i[0]);
-        cluster_axis(R->vlines, R->n_vlines, s_sorted, gp.min_grid_spacing, R->vcentres, &s_i[1]);
+        cluster_axis(R->hlines, R->n_hlines, s_sorted, gp.min_grid_spacing, s_cen[0], &s_i[0]);
+        cluster_axis(R->vlines, R->n_vlines, s_sorted, gp.min_grid_spacing, s_cen[1], &s_i[1]);
         if (tid == 0) {
             int status = 0;
             const int nh = s_i[0], nv = s_i[1];
@@ -159,23 +162,23 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
                 // validate_grid (:420-445): horizontal lines first
                 int first = 0, m = 0;
                 int n = truncate_grid(nh, &first);
-                int rc = complete_grid(R->hcentres + first, n, s_tmp[0], &m, gp.min_grid_spacing, gp.big_space_ratio);
+                int rc = complete_grid(s_cen[0] + first, n, s_tmp[0], &m, gp.min_grid_spacing, gp.big_space_ratio);
                 if (rc) status = rc;
                 else {
                     int f2 = 0;
                     const int mh = truncate_grid(m, &f2);
-                    for (int i = 0; i < mh; i++) R->hcentres_complete[i] = s_tmp[0][f2 + i];
+                    for (int i = 0; i < mh; i++) s_cmp[0][i] = s_tmp[0][f2 + i];
                     first = 0;
                     n = truncate_grid(nv, &first);
-                    rc = complete_grid(R->vcentres + first, n, s_tmp[1], &m, gp.min_grid_spacing, gp.big_space_ratio);
+                    rc = complete_grid(s_cen[1] + first, n, s_tmp[1], &m, gp.min_grid_spacing, gp.big_space_ratio);
                     if (rc) status = rc + (I2S_ST_V_NO_LINES - I2S_ST_H_NO_LINES);
                     else {
                         f2 = 0;
                         const int mv = truncate_grid(m, &f2);
-                        for (int i = 0; i < mv; i++) R->vcentres_complete[i] = s_tmp[1][f2 + i];
+                        for (int i = 0; i < mv; i++) s_cmp[1][i] = s_tmp[1][f2 + i];
                         const int vsize = mh, hsize = mv;    // number of horizontal lines = vertical size (:435-436)
-                        const double hspace = (R->hcentres_complete[mh - 1] - R->hcentres_complete[0]) / (double)vsize;
-                        const double vspace = (R->vcentres_complete[mv - 1] - R->vcentres_complete[0]) / (double)hsize;
+                        const double hspace = (s_cmp[0][mh - 1] - s_cmp[0][0]) / (double)vsize;
+                        const double vspace = (s_cmp[1][mv - 1] - s_cmp[1][0]) / (double)hsize;
                         s_tmp[0][0] = (hspace < vspace ? hspace : vspace) * 0.3;     // min_circle_size (:441)
                         s_tmp[0][1] = (hspace > vspace ? hspace : vspace) * 0.65;    // max_circle_size (:442)
                         s_i[4] = 1;
@@ -190,6 +193,10 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
             s_i[5] = 0;
         }
         __syncthreads();
+        for (int i = tid; i < R->n_hcentres; i += 256) R->hcentres[i] = s_cen[0][i];
+        for (int i = tid; i < R->n_vcentres; i += 256) R->vcentres[i] = s_cen[1][i];
+        for (int i = tid; i < R->n_hcomplete; i += 256) R->hcentres_complete[i] = s_cmp[0][i];
+        for (int i = tid; i < R->n_vcomplete; i += 256) R->vcentres_complete[i] = s_cmp[1][i];
         {
             // radius filter (:443), all threads; a failed validation returns `circles` unfiltered (:426)
             const bool filt = s_i[4] != 0;
@@ -207,6 +214,11 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
         if (tid == 0) R->n_circles_kept = s_i[5];
         __syncthreads();
     }
+    if (!do_cluster) {
+        for (int i = tid; i < R->n_hcomplete; i += 256) s_cmp[0][i] = R->hcentres_complete[i];
+        for (int i = tid; i < R->n_vcomplete; i += 256) s_cmp[1][i] = R->vcentres_complete[i];
+        __syncthreads();
+    }
     // identify_board (:497-543)
     const bool ready = R->valid_grid && R->hsize <= I2S_BOARD_SIZE && R->vsize <= I2S_BOARD_SIZE && R->status != I2S_ST_CAPACITY;
     const int hsize = R->hsize, vsize = R->vsize;
@@ -215,8 +227,8 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
     if (ready) {
         for (int i = tid; i < R->n_circles; i += 256) {
             if (!R->circle_kept[i]) continue;
-            const int ci = closest_index((double)R->circles[i][0], R->vcentres_complete, hsize);
-            const int cj = closest_index((double)R->circles[i][1], R->hcentres_complete, vsize);
+            const int ci = closest_index((double)R->circles[i][0], s_cmp[1], hsize);
+            const int cj = closest_index((double)R->circles[i][1], s_cmp[0], vsize);
             s_det[ci][cj] = I2S_STONE;
         }
     }
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
                 for (int k = 0; k < vsize; k++)
                     if (s_det[j][k] == I2S_STONE) {
                         // average_intensity (:468-481); note x uses hspace, y uses vspace (reference quirk)
-                        const double x = R->vcentres_complete[j], y = R->hcentres_complete[k];
+                        const double x = s_cmp[1][j], y = s_cmp[0][k];
                         int xmin = (int)rint(x - hspace / 2), xmax = (int)rint(x + hspace / 2);
                         int ymin = (int)rint(y - vspace / 2), ymax = (int)rint(y + vspace / 2);
                         xmin = imax(0, xmin); ymin = imax(0, ymin); xmax = imin(w, xmax); ymax = imin(h, ymax);
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
             for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
             if (s < ns && lane == 0) {
                 // np.mean of uint8: float64 sum / count; empty slice -> nan (compares False -> WHITE)
-                R->brightness[s] = cnt > 0 ? (double)sum / (double)cnt : __builtin_nan("");
+                s_br[s] = cnt > 0 ? (double)sum / (double)cnt : __builtin_nan("");
             }
         }
     }
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
             for (int j = 0; j < hsize; j++)
                 for (int k = 0; k < vsize; k++)
                     if (s_det[j][k] == I2S_STONE) {
-                        const bool black = R->brightness[s] <= thr;
+                        const bool black = s_br[s] <= thr;
                         s_det[j][k] = black ? I2S_BLACK : I2S_WHITE;
                         nblack += black ? 1 : 0;
                         s++;
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
         s_i[3] = ready ? 1 : 0;
     }
     __syncthreads();
+    for (int i = tid; i < ns; i += 256) R->brightness[i] = s_br[i];
     // align_board (:484-494) + publish
     const int xoff = (gp.align_x == I2S_ALIGN_RIGHT) ? I2S_BOARD_SIZE - hsize : 0;
     const int yoff = (gp.align_y == I2S_ALIGN_BOTTOM) ? I2S_BOARD_SIZE - vsize : 0;
