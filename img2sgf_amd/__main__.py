@@ -1,0 +1,53 @@
+"""Headless counterpart of the reference's command line (img2sgf.py:1256-1269):
+
+    python -m img2sgf_amd input.jpg [output.sgf]
+
+opens the image, applies the reference's default settings (img2sgf.py:616-640: contrast 70, brightness 50, no rotation,
+full-image selection, Hough threshold from choose_threshold, black threshold 128, alignment left/top), runs the board
+detection on the GPU and writes what the reference's "save" button writes (to_SGF, :781-822).  Several inputs may be
+given with -o DIR; they are detected as one batch."""
+import argparse
+import os
+import sys
+
+from . import pipeline, preprocess
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m img2sgf_amd", description=__doc__.split("\n\n")[0])
+    ap.add_argument("inputs", nargs="+", help="image file(s); with one input a second positional argument is the output .sgf")
+    ap.add_argument("-o", "--outdir", help="directory for <name>.sgf when several inputs are given")
+    ap.add_argument("--contrast", type=int, default=preprocess.CONTRAST_DEFAULT)
+    ap.add_argument("--brightness", type=int, default=preprocess.BRIGHTNESS_DEFAULT)
+    ap.add_argument("--threshold", type=int, default=0, help="Hough-lines threshold (0 = choose_threshold)")
+    ap.add_argument("--black-threshold", type=int, default=128)
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args(argv)
+    inputs, out_single = args.inputs, None
+    if len(inputs) == 2 and inputs[1].lower().endswith(".sgf") and not args.outdir:
+        inputs, out_single = inputs[:1], inputs[1]
+    images = [preprocess.load_and_enhance(p, args.contrast, args.brightness) for p in inputs]
+    det = pipeline.Detector(args.device, min(len(images), 16), max(i.shape[1] for i in images), max(i.shape[0] for i in images))
+    params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold)
+    rc = 0
+    for path, d in zip(inputs, det.detect_batch(images, params)):
+        name = os.path.splitext(os.path.basename(path))[0] + ".sgf"
+        out = out_single or (os.path.join(args.outdir, name) if args.outdir else None)
+        if not d.board_ready:
+            print("%s: board not detected (%s)" % (path, d.status_text), file=sys.stderr)
+            rc = 1
+            continue
+        print("%s: %dx%d board, %d black + %d white stones, %s to play" % (
+            path, d.hsize, d.vsize, d.num_black_stones, d.num_white_stones, "black" if d.side_to_move == 1 else "white"),
+            file=sys.stderr)
+        if out:
+            with open(out, "w") as f:
+                f.write(d.sgf)
+        else:
+            sys.stdout.write(d.sgf)
+    det.close()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

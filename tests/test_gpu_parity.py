@@ -134,3 +134,11 @@ def test_device_resident_batch_properties():
         assert bytes(ba[k]) == bytes(bb[k]) == bytes(ba2[k])
     det_a.close()
     det_b.close()
+
+
+def test_headless_cli(tmp_path):
+    """python -m img2sgf_amd ex1.jpg out.sgf == the reference's recorded result for ex1."""
+    from img2sgf_amd.__main__ import main
+    out = tmp_path / "ex1.sgf"
+    assert main([os.path.join(GOLDEN, "test_images", "ex1.jpg"), str(out)]) == 0
+    assert out.read_text() == EX1_SGF
