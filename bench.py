@@ -72,8 +72,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # launched by torch.distributed.run: always go through RCCL
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     B = args.batch
@@ -93,7 +96,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -105,7 +108,7 @@ def main():
         allb = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -146,7 +149,7 @@ def main():
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_images)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -26,10 +26,10 @@ def allgather_boards(boards, world=1, device_index=None):
     """All ranks contribute their (n_r, 384) board records and receive the concatenation in rank order.
     Shards may differ by one record (shard_range), so records are padded to the largest shard for the collective."""
     mine = boards_to_numpy(boards)
-    if world == 1:
+    import torch.distributed as dist
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return mine.copy()
     import torch
-    import torch.distributed as dist
     backend = dist.get_backend()
     dev = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
     counts = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)

@@ -142,3 +142,49 @@ def test_headless_cli(tmp_path):
     out = tmp_path / "ex1.sgf"
     assert main([os.path.join(GOLDEN, "test_images", "ex1.jpg"), str(out)]) == 0
     assert out.read_text() == EX1_SGF
+
+
+def test_bench_under_torchrun_single_rank():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, RCCL backend), with one rank:
+    process-group init, barrier, max-over-ranks all-reduce and the board all-gather all go through RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(GOLDEN))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--batch", "96", "--pass-size", "32", "--streams", "2", "--roofline-images", "32", "--no-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["config"]["boards_match_generator"] is True and d["value"] > 0
+    assert d["roofline"]["frac"] > 0 and d["unit"] == "images/s"
+
+
+def test_capacity_overflow_is_reported_not_truncated():
+    """More Hough-line peaks than I2S_MAX_LINES: the image must come back with status CAPACITY, never silently cut."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (1024, 1024), dtype=np.uint8)
+    det = Detector(0, 1, 1024, 1024)
+    d = det.detect_batch([img], Params(line_threshold=1))[0]
+    assert d.status == 100 and not d.board_ready and d.sgf is None
+    det.close()
+
+
+def test_hysteresis_pass_budget_growth():
+    """A weak edge that snakes through many tiles and is anchored by a single strong seed needs more hysteresis passes than
+    the initial budget: the pass is redone with a doubled budget and the result still equals the oracle exactly."""
+    h, w = 256, 512
+    img = np.full((h, w), 100, np.uint8)
+    # serpentine of low-contrast steps (magnitude 4*30 = 120: weak for 50/200) ...
+    for k, y in enumerate(range(20, h - 20, 24)):
+        img[y:y + 12, 10:w - 10] = 130
+    for k, y in enumerate(range(20, h - 44, 24)):
+        x = w - 30 if k % 2 == 0 else 10
+        img[y:y + 36, x:x + 20] = 130
+    # ... with one strong seed (magnitude > 200) at its start
+    img[20:32, 10:14] = 255
+    det = Detector(0, 1, w, h)
+    parity.run_and_compare(det, [img], internals=False)
+    det.close()
