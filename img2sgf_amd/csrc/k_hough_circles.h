@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
                                                       int* __restrict__ dbg_acc, int gx, int gy)
 {
     __shared__ unsigned s_acc[(VL / 2) * VASTR];
+    __shared__ int s_ticket;
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z / NVAR, v = tl.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
     const int tid = threadIdx.x;
     const int bv = b * NVAR + v;
     for (int i = tid; i < (VL / 2) * VASTR; i += VTHREADS) s_acc[i] = 0;
+    if (tid == 0) s_ticket = VTHREADS / 64;        // bins 0 .. 7 are taken by the waves' first round
     __syncthreads();
     // LDS tile covers cells [lx0, lx0 + VL) x [ly0, ly0 + VL); edge pixels within max_r of it can vote into it
     const int lx0 = cx0 - 1, ly0 = cy0 - 1;
@@ -152,37 +154,38 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
     const size_t bin_base = (size_t)bv * g.bins;
     // one wavefront per bin: a coalesced 512-byte load brings 64 edge records, every lane tests whether ITS record's
     // ray segment (+-max_r steps) can touch the tile at all, then the wave walks the surviving records one by one
-    // (record broadcast through v_readlane, i.e. in scalar registers).  The reach window spans at most 7 x 7 bins, so a
-    // wave owns at most 7 of them: their counts come from one lane-indexed load and the first 64 records of ALL of them
-    // are requested up front, so the memory latency is paid once per workgroup, not once per bin.
-    constexpr int WB = 7;                                   // ceil(49 / 8) bins per wave
+    // (record broadcast through v_readlane, i.e. in scalar registers).  The reach window spans at most 7 x 7 bins; their
+    // counts come from one lane-indexed load.  Bins are handed out dynamically (LDS ticket) because their populations
+    // differ a lot (grid lines concentrate in a few bins): with a static split the waves of a workgroup spent 40 % of
+    // their time waiting for the slowest one at the barrier.  Each wave keeps one bin in flight ahead of the one it walks.
     int my_cnt = 0;
     if (lane < nbin) my_cnt = bin_cnt[bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx)];
-    uint2 pre[WB];
-    int cnt[WB];
-#pragma unroll
-    for (int i = 0; i < WB; i++) {
-        const int q = wave + i * (VTHREADS / 64);
-        pre[i] = make_uint2(0u, 0u);
-        cnt[i] = 0;
-        if (q < nbin) {
-            cnt[i] = __builtin_amdgcn_readlane(my_cnt, q);
-            const uint2* ent = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
-            if (lane < cnt[i]) pre[i] = ent[lane];
-        }
+    int q = wave;                                   // first round: bin == wave index, later rounds: ticket
+    int n_cur = 0;
+    const uint2* ent_cur = bin_ent;
+    uint2 mine = make_uint2(0u, 0u);
+    if (q < nbin) {
+        n_cur = __builtin_amdgcn_readlane(my_cnt, q);
+        ent_cur = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+        if (lane < n_cur) mine = ent_cur[lane];
     }
-#pragma unroll
-    for (int i = 0; i < WB; i++) {
-        const int q = wave + i * (VTHREADS / 64);
-        const int n_cur = cnt[i];
-        if (q >= nbin || n_cur == 0) continue;
-        const uint2* ent_cur = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
-        uint2 mine = pre[i];
+    while (q < nbin) {
+        int qn = 0;
+        if (lane == 0) qn = atomicAdd(&s_ticket, 1);
+        qn = __builtin_amdgcn_readlane(qn, 0);
+        int n_next = 0;
+        const uint2* ent_next = bin_ent;
+        uint2 mine_next = make_uint2(0u, 0u);
+        if (qn < nbin) {
+            n_next = __builtin_amdgcn_readlane(my_cnt, qn);
+            ent_next = bin_ent + (bin_base + (size_t)(by0 + qn / nbx) * g.bw + (bx0 + qn % nbx)) * EB_CAP;
+            if (lane < n_next) mine_next = ent_next[lane];
+        }
         for (int k0 = 0; k0 < n_cur; k0 += 64) {
             if (k0 > 0) { mine = make_uint2(0u, 0u); if (k0 + lane < n_cur) mine = ent_cur[k0 + lane]; }
             // lane-parallel: unpack MY record (position relative to the first valid cell in 1/1024 px, step vector) and
             // test whether its ray segment can touch the tile; the walk below then needs no scalar unpacking at all
-            // (the scalar ALU is shared by the CU's four SIMDs and was the bottleneck of this loop).
+            // (the scalar ALU is shared by the CU's four SIMDs).
             const int sxv = (int)(short)(mine.y & 0xffffu), syv = (int)(short)(mine.y >> 16);
             const int exr = (int)(mine.x & 0xffffu) - vx_lo, eyr = (int)(mine.x >> 16) - vy_lo;
             const int X0v = exr << 10, Y0v = eyr << 10;
@@ -193,9 +196,6 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
                 reach = exr + ddx >= 0 && exr - ddx < (int)vx_n && eyr + ddy >= 0 && eyr - ddy < (int)vy_n;
             }
             unsigned long long m = __ballot(reach);
-#ifdef I2S_EXP_NOWALK
-            if (cent_count != nullptr) m = 0;
-#endif
             while (m) {
                 const int j = __builtin_ctzll(m);
                 m &= ~(1ull << j);
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
                 }
             }
         }
+        q = qn; n_cur = n_next; ent_cur = ent_next; mine = mine_next;
     }
     __syncthreads();
     // centre candidates: cells (x,y), 1 <= x <= w-1, 1 <= y <= h-1 (OpenCV scans padded rows 1..H, cols 1..W
@@ -225,16 +226,31 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
 #ifdef I2S_EXP_NOCENTRE
     if (cent_count != nullptr) return;
 #endif
-    for (int i = tid; i < VT * VT; i += VTHREADS) {
-        const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
-        const int x = lx0 + tx, y = ly0 + ty;
-        if (x >= w || y >= h) continue;
-        const int a = I2S_CELL(tx, ty);
-        if (dbg_acc) dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = a;
-        if (a <= acc_thr || x < 1 || y < 1) continue;
-        if (a > I2S_CELL(tx - 1, ty) && a >= I2S_CELL(tx + 1, ty) && a > I2S_CELL(tx, ty - 1) && a >= I2S_CELL(tx, ty + 1)) {
-            const int k = atomicAdd(&cent_count[bv], 1);
-            if (k < CENT_CAP) cent_list[(size_t)bv * CENT_CAP + k] = (unsigned)x | ((unsigned)y << 16);
+    if (dbg_acc) {
+        for (int i = tid; i < VT * VT; i += VTHREADS) {
+            const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
+            const int x = lx0 + tx, y = ly0 + ty;
+            if (x < w && y < h) dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = I2S_CELL(tx, ty);
+        }
+    }
+    // one dword = cells (tx, r6) and (tx, r6 + 64): almost all hold fewer votes than the threshold and are rejected in pairs
+    for (int i = tid; i < 64 * VT; i += VTHREADS) {
+        const int r6 = i / VT, tx = i - r6 * VT + 1;
+        const unsigned v2 = s_acc[r6 * VASTR + tx];
+        if ((int)(v2 & 0xffffu) <= acc_thr && (int)(v2 >> 16) <= acc_thr) continue;
+        const int x = lx0 + tx;
+        if (x >= w || x < 1) continue;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int ty = r6 + 64 * hh;
+            if (ty < 1 || ty > VT) continue;
+            const int a = hh ? (int)(v2 >> 16) : (int)(v2 & 0xffffu);
+            const int y = ly0 + ty;
+            if (a <= acc_thr || y >= h || y < 1) continue;
+            if (a > I2S_CELL(tx - 1, ty) && a >= I2S_CELL(tx + 1, ty) && a > I2S_CELL(tx, ty - 1) && a >= I2S_CELL(tx, ty + 1)) {
+                const int k = atomicAdd(&cent_count[bv], 1);
+                if (k < CENT_CAP) cent_list[(size_t)bv * CENT_CAP + k] = (unsigned)x | ((unsigned)y << 16);
+            }
         }
     }
 #undef I2S_CELL
