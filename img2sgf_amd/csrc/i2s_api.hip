@@ -324,14 +324,15 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL((k_gauss<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3), t3, fx, fy);
         hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5, fx, fy);
         hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7, fx, fy);
-        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, g_f, b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, ctx->d_weak, fx, fy);
+        const int ngx = cdiv(fx, NMS_TPB);                             // groups of NMS_TPB tiles along x
+        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, ctx->d_weak, ngx, fy);
         if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, ctx->d_weak, fx, fy);
         rc = run_hysteresis(ctx, 0, 0, 1, fx, fy);
         if (rc) return rc;
         hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES), rx, ry);
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
-        hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)fx * fy * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo,
-                           p->hc_param1, 0, ctx->d_weak, fx, fy);
+        hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo,
+                           p->hc_param1, 0, ctx->d_weak, ngx, fy);
         rc = run_hysteresis(ctx, 1, 1, NVAR, fx, fy);
         if (rc) return rc;
         hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,

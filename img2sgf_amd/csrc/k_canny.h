@@ -10,6 +10,7 @@ namespace i2s {
 
 constexpr int CT_W = 64;   // NMS output tile
 constexpr int CT_H = 32;
+constexpr int NMS_TPB = 4;  // consecutive tiles (along x) handled by one workgroup of k_sobel_nms_planes, software-pipelined
 // hysteresis works on the same 64 x 32 tiles; weak[(m * nb + b) * g.tiles + ty * g.tw + tx] != 0 iff the tile holds weak pixels
 
 // Sobel + NMS of one tile.  src(y,x,c) = sp[y*sstride + x*CN + c].
@@ -116,19 +117,28 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     constexpr int MROWS = CT_H + 2, MSTRIPS = CT_W / 4 + 2, MSTR = 2 * MSTRIPS + 1;   // mag rows y0-1.., x0-4 .. x0+68 (u16 pairs)
     __shared__ unsigned s_src[SROWS * SSTR];
     __shared__ unsigned s_mag[MROWS * MSTR];
+    // gx counts GROUPS of NMS_TPB tiles; the workgroup walks its group left to right and fetches tile t+1 into registers
+    // while it computes tile t (the tile kernels are otherwise latency-bound: load -> wait -> compute -> store)
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z % g.nb;
     const int v = main_mode ? 0 : v_first + tl.z / g.nb;
     if (main_mode && desc[b].cn != 1) return;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = tl.tx * CT_W, y0 = tl.ty * CT_H;
-    if (x0 >= w || y0 >= h) return;
+    const int y0 = tl.ty * CT_H;
+    if (tl.tx * NMS_TPB * CT_W >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const uint8_t* plane = planes + ((size_t)v * g.nb + b) * g.slot;
     uint8_t* mp = maps + ((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.slot;
+    TileRegs<SROWS, SWORDS, 256, BORDER_REPL> pre;
+    pre.fetch(plane, g.pitch, w, h, tl.tx * NMS_TPB * CT_W - 8, y0 - 2, tid);
+    for (int tt = 0; tt < NMS_TPB; tt++) {
+    const int tile_x = tl.tx * NMS_TPB + tt;
+    const int x0 = tile_x * CT_W;
+    if (x0 >= w) break;
     if (tid == 0) s_weak = 0;
-    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, plane, g.pitch, w, h, x0 - 8, y0 - 2, tid);
+    pre.park<SSTR>(s_src, tid);
     __syncthreads();
+    if (tt + 1 < NMS_TPB && x0 + CT_W < w) pre.fetch(plane, g.pitch, w, h, x0 + CT_W - 8, y0 - 2, tid);
     // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry.
     // Two pixels per register (16-bit lanes, v_pk_* instructions): column sums / row differences of the 3x6
     // neighbourhood, then dx = col[+1] - col[-1], dy = dif[-1] + 2 dif[0] + dif[+1], mag = |dx| + |dy|.
@@ -234,7 +244,8 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
         if (wk) s_weak = 1;
     }
     __syncthreads();
-    if (tid == 0) weak[((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tl.tx] = s_weak;
+    if (tid == 0) weak[((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x] = s_weak;
+    }   // tiles of the group
 }
 
 // One hysteresis pass over maps [m_first, m_first + gridDim.z / nb).  Each block brings its 64x32 tile (with a read-only
