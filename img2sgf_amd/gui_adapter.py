@@ -1,0 +1,97 @@
+"""Drop-in adapter for the reference's Tk application.
+
+    import img2sgf                      # the reference module, unmodified
+    import img2sgf_amd.gui_adapter as adapter
+    adapter.install(img2sgf)            # process_image() / identify_board() now run on the GPU
+
+`install(m)` replaces the two functions through which the GUI enters the hot path -- `process_image`
+(img2sgf.py:117-204, called from 639, 723, 1077, 1134, 1140, 1178, 1181, 1191) and `identify_board` (497-543, called
+from apply_black_thresh 765) -- with versions that run the detection through the C ABI and then assign exactly the
+module globals the rest of the reference reads (draw_images 862-897, draw_board 900-952, draw_histogram 207-227,
+cluster plotting 308-327, edit_board 955-1002, to_SGF 781-810).  Everything else (Tk widgets, Pillow pre-processing,
+logging, the board editor) keeps running the reference's own code.
+"""
+import numpy as np
+
+from . import pipeline
+
+
+def install(m, detector=None, lib=None):
+    """Patch reference module `m` in place.  Returns the Detector in use."""
+    state = {"det": detector, "lib": lib}
+
+    def _detector(w, h):
+        d = state["det"]
+        if d is None or d.max_w < w or d.max_h < h:
+            if d is not None:
+                d.close()
+            d = state["det"] = pipeline.Detector(0, 1, max(w, 1024), max(h, 1024), lib=state["lib"])
+        return d
+
+    def _params():
+        return pipeline.Params(
+            canny_lo=int(m.edge_min.get()), canny_hi=int(m.edge_max.get()),      # img2sgf.py:163
+            line_threshold=int(m.threshold.get()),                               # :259
+            black_threshold=int(m.black_stone_threshold),                        # :515, 541
+            alignment=(int(m.board_alignment[0]), int(m.board_alignment[1])))    # :543
+
+    def _publish_board(det):
+        m.detected_board = det.detected_board
+        m.full_board = det.full_board
+        m.stone_brightnesses = det.stone_brightnesses
+        m.num_black_stones, m.num_white_stones = det.num_black_stones, det.num_white_stones
+        m.side_to_move.set(det.side_to_move)                                     # :529-534
+
+    def process_image():
+        """img2sgf.py:117-204 with the OpenCV section (153-198) and find_grid() (546-576) on the GPU."""
+        if not m.image_loaded:
+            return
+        m.found_grid = m.valid_grid = m.board_ready = False
+        m.log("\nProcessing image")
+        m.crop_and_rotate_image()                                                # :136 (Pillow, host)
+        if m.rotate_angle.get() != 0:
+            m.log("Rotated by " + str(m.rotate_angle.get()) + " degrees")
+        from PIL import Image, ImageEnhance
+        m.log("Contrast = " + str(m.contrast.get()))
+        region = ImageEnhance.Contrast(m.region_PIL).enhance(102 / (101 - m.contrast.get()) - 1)       # :142-144
+        m.log("Brightness = " + str(m.brightness.get()))
+        region = ImageEnhance.Brightness(region).enhance(450 / (200 - m.brightness.get()) - 2)         # :147-149
+        m.region_PIL = region
+        m.input_image_np = np.array(region)                                                           # :150
+        m.log("Converting to greyscale / Canny / detecting circles / finding grid on the GPU")
+        h, w = m.input_image_np.shape[:2]
+        d = _detector(w, h)
+        det = d.detect_batch([m.input_image_np], _params(), full=True)[0]
+        m.grey_image_np = d.fetch_plane(0, "grey")                                                     # :153
+        m.edge_detected_image_np = d.fetch_plane(0, "edges")                                           # :162
+        m.edge_detected_image_PIL = Image.fromarray(m.edge_detected_image_np)                          # :166
+        m.circles_removed_image_np = d.fetch_plane(0, "removed")                                       # :169-198
+        m.circles_removed_image_PIL = Image.fromarray(m.circles_removed_image_np)                      # :200
+        # find_grid() results (:546-576)
+        m.hcentres, m.vcentres = det.hcentres, det.vcentres
+        m.found_grid, m.valid_grid, m.board_ready = det.found_grid, det.valid_grid, det.board_ready
+        m.circles = det.circles if len(det.circles) else []                      # filtered when the grid is valid (:554)
+        m.vsize, m.hsize = det.vsize, det.hsize
+        m.hcentres_complete, m.vcentres_complete = det.hcentres_complete, det.vcentres_complete
+        m.hspace, m.vspace = det.hspace, det.vspace
+        m.log("Found " + str(len(det.hlines)) + " distinct horizontal lines and " + str(len(det.vlines)) +
+              " distinct vertical lines")                                         # :263
+        if det.board_ready:
+            _publish_board(det)
+            m.save_button.configure(state=m.tk.ACTIVE)                           # :575
+        else:
+            m.log("Board not detected: " + det.status_text)
+        m.draw_board()                                                           # :576
+        m.draw_images()                                                          # :203
+        m.draw_histogram(m.stone_brightnesses)                                   # :204
+
+    def identify_board():
+        """img2sgf.py:497-543 on the cached detection (apply_black_thresh, :762-766)."""
+        d = state["det"]
+        det = d.classify(0, 1, _params())[0]
+        _publish_board(det)
+        m.draw_histogram(m.stone_brightnesses)                                   # :535
+
+    m.process_image = process_image
+    m.identify_board = identify_board
+    return state
