@@ -26,9 +26,11 @@ def main(argv=None):
     inputs, out_single = args.inputs, None
     if len(inputs) == 2 and inputs[1].lower().endswith(".sgf") and not args.outdir:
         inputs, out_single = inputs[:1], inputs[1]
-    images = [preprocess.load_and_enhance(p, args.contrast, args.brightness) for p in inputs]
+    import numpy as np
+    images = [np.array(preprocess.load_image(p)) for p in inputs]        # decoded RGB; contrast / brightness run on the GPU
     det = pipeline.Detector(args.device, min(len(images), 16), max(i.shape[1] for i in images), max(i.shape[0] for i in images))
-    params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold)
+    params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
+                             contrast=args.contrast, brightness=args.brightness)
     rc = 0
     for path, d in zip(inputs, det.detect_batch(images, params)):
         name = os.path.splitext(os.path.basename(path))[0] + ".sgf"

@@ -37,6 +37,7 @@ class I2sParams(C.Structure):
         ("min_grid_spacing", C.c_double), ("big_space_ratio", C.c_double), ("angle_tolerance_deg", C.c_double),
         ("grey_shift", C.c_int32), ("gauss_kernel_mode", C.c_int32), ("houghlines_numangle_mode", C.c_int32),
         ("inputs_on_device", C.c_int32),
+        ("contrast", C.c_int32), ("brightness", C.c_int32),
     ]
 
 
@@ -79,7 +80,7 @@ assert C.sizeof(I2sResult) == 73384
 
 EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
            "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_classify_batch", "i2s_grid_from_lines",
-           "i2s_fetch_plane", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc"]
+           "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc"]
 
 
 class I2sError(RuntimeError):
@@ -118,6 +119,7 @@ class I2sLibrary:
         L.i2s_grid_from_lines.argtypes = [vp, u8p, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int,
                                           C.POINTER(I2sParams), C.POINTER(I2sBoard), C.POINTER(I2sResult)]
         L.i2s_fetch_plane.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.i2s_fetch_source.argtypes = [vp, C.c_int, u8p, C.c_size_t]
         L.i2s_last_timing.argtypes = [vp, f32p]
         L.i2s_set_debug.argtypes = [vp, C.c_int]
         L.i2s_fetch_circle_acc.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int32)]

@@ -14,6 +14,7 @@
 #include "k_filters.h"
 #include "k_grid.h"
 #include "k_hough_circles.h"
+#include "k_preprocess.h"
 
 using namespace i2s;
 
@@ -39,6 +40,8 @@ struct i2s_ctx {
     int* d_counts = nullptr;     // cent_count | est_count | vcount | overflow
     unsigned long long* d_est_keys = nullptr;
     float* d_vcirc = nullptr;
+    unsigned long long* d_lsum = nullptr;   // [nb] luma sums for the contrast step
+    int last_staged = 0;
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
     int* d_weak = nullptr;       // [NMAP][nb][tiles] tile holds weak pixels
@@ -87,6 +90,7 @@ extern "C" void i2s_default_params(i2s_params* p)
     p->align_x = I2S_ALIGN_LEFT; p->align_y = I2S_ALIGN_TOP;
     p->min_grid_spacing = 10; p->big_space_ratio = 1.6; p->angle_tolerance_deg = 1.0;
     p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 0; p->inputs_on_device = 0;
+    p->contrast = -1; p->brightness = -1;
 }
 
 // choose_threshold (img2sgf.py:606-613)
@@ -117,7 +121,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -144,6 +148,7 @@ static int create_impl(i2s_ctx* ctx)
     g.tw = (ctx->max_w + CT_W - 1) / CT_W;
     g.tiles = g.tw * ((ctx->max_h + CT_H - 1) / CT_H);
     const size_t nb = ctx->max_batch;
+    I2S_HIP(hipMalloc(&ctx->d_lsum, nb * sizeof(unsigned long long)));
     I2S_HIP(hipMalloc(&ctx->d_tl_cnt, nb * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(unsigned short)));
     I2S_HIP(hipMalloc(&ctx->d_weak, nb * NMAP * g.tiles * sizeof(int)));
@@ -257,6 +262,7 @@ static int check_params(const i2s_params* p)
         return I2S_E_UNSUPPORTED;
     if (p->hc_param2 < 0 || p->hc_param1 < 1 || p->canny_lo > p->canny_hi) return I2S_E_UNSUPPORTED;
     if (p->grey_shift != 15 && p->grey_shift != 14) return I2S_E_UNSUPPORTED;
+    if (p->contrast > 100 || p->brightness > 100) return I2S_E_UNSUPPORTED;
     return I2S_OK;
 }
 
@@ -298,6 +304,16 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     gauss_taps(7, 7, p->gauss_kernel_mode, &t7);
     const int hc_lo = p->hc_param1 / 2 > 1 ? p->hc_param1 / 2 : 1;
     const GridParams gp = grid_params(p);
+    if (p->contrast >= 0 || p->brightness >= 0) {
+        // ImageEnhance.Contrast / .Brightness (img2sgf.py:141-149) in place on the staged sources -- ONCE per pass, outside
+        // the redo loop below (a redone pass must not enhance the image a second time)
+        const float fc = p->contrast >= 0 ? (float)(102.0 / (101 - p->contrast) - 1) : 1.0f;
+        const float fb = p->brightness >= 0 ? (float)(450.0 / (200 - p->brightness) - 2) : 1.0f;
+        I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
+        I2S_HIP(hipMemsetAsync(ctx->d_lsum, 0, nb * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_luma_sum, dim3(cdiv(hmax, 8), nb), dim3(256), 0, st, ctx->d_desc, ctx->d_lsum);
+        hipLaunchKernelGGL(k_enhance, dim3(cdiv(wmax * 3, 1024), hmax, nb), dim3(256), 0, st, ctx->d_desc, ctx->d_lsum, fc, fb);
+    }
 
     for (;;) {
         I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
@@ -378,6 +394,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     I2S_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
     ctx->timing[4] += ms;
     ctx->last_nb = nb;
+    ctx->last_staged = (!p->inputs_on_device || p->contrast >= 0 || p->brightness >= 0) ? 1 : 0;
     return I2S_OK;
 }
 
@@ -404,11 +421,14 @@ extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, 
             ImgDesc& d = ctx->h_desc[i];
             d.w = w[k]; d.h = h[k]; d.cn = channels[k]; d.pad = 0;
             d.line_thr = p->line_threshold > 0 ? p->line_threshold : i2s_choose_threshold(w[k], h[k]);
-            if (p->inputs_on_device) { d.src = img[k]; d.sstride = stride[k]; }
+            const bool enhance = p->contrast >= 0 || p->brightness >= 0;
+            if (p->inputs_on_device && !enhance) { d.src = img[k]; d.sstride = stride[k]; }
             else {
+                // staged copy (host inputs; device inputs that the contrast / brightness step will modify)
                 uint8_t* dst = ctx->d_src + (size_t)i * ctx->src_slot;
                 const size_t rowb = (size_t)w[k] * channels[k];
-                I2S_HIP(hipMemcpy2DAsync(dst, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k], hipMemcpyHostToDevice, ctx->stream));
+                I2S_HIP(hipMemcpy2DAsync(dst, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k],
+                                         p->inputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
                 d.src = dst; d.sstride = (int)rowb;
             }
             wmax = w[k] > wmax ? w[k] : wmax; hmax = h[k] > hmax ? h[k] : hmax;
@@ -476,6 +496,17 @@ extern "C" int i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* d
     if (dst_stride < (size_t)d.w) return I2S_E_INVALID;
     const uint8_t* src = plane_ptr(ctx, plane_id) + (size_t)index * ctx->geo.slot;
     I2S_HIP(hipMemcpy2DAsync(dst, dst_stride, src, ctx->geo.pitch, d.w, d.h, hipMemcpyDeviceToHost, ctx->stream));
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
+    return I2S_OK;
+}
+
+extern "C" int i2s_fetch_source(i2s_ctx* ctx, int index, uint8_t* dst, size_t dst_stride)
+{
+    if (!ctx || !dst || index < 0 || index >= ctx->last_nb || !ctx->last_staged) return I2S_E_INVALID;
+    const ImgDesc& d = ctx->h_desc[index];
+    const size_t rowb = (size_t)d.w * d.cn;
+    if (dst_stride < rowb) return I2S_E_INVALID;
+    I2S_HIP(hipMemcpy2DAsync(dst, dst_stride, d.src, (size_t)d.sstride, rowb, d.h, hipMemcpyDeviceToHost, ctx->stream));
     I2S_HIP(hipStreamSynchronize(ctx->stream));
     return I2S_OK;
 }

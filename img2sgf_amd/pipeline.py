@@ -40,6 +40,8 @@ class Params:
     grey_shift: int = 15               # OpenCV-version switches
     gauss_kernel_mode: int = 0
     houghlines_numangle_mode: int = 0
+    contrast: Optional[int] = None     # 0..100: ImageEnhance.Contrast on the device (img2sgf.py:141-144); None = input is already enhanced
+    brightness: Optional[int] = None   # 0..100: ImageEnhance.Brightness on the device (:146-149)
 
     def to_c(self, inputs_on_device=False):
         p = I2sParams()
@@ -54,6 +56,8 @@ class Params:
         p.grey_shift, p.gauss_kernel_mode = self.grey_shift, self.gauss_kernel_mode
         p.houghlines_numangle_mode = self.houghlines_numangle_mode
         p.inputs_on_device = 1 if inputs_on_device else 0
+        p.contrast = -1 if self.contrast is None else int(self.contrast)
+        p.brightness = -1 if self.brightness is None else int(self.brightness)
         return p
 
 
@@ -217,6 +221,13 @@ class Detector:
         h, w = self._last_shapes[index][:2]
         out = np.empty((h, w), np.uint8)
         self._check(self.lib.dll.i2s_fetch_plane(self._ctx, index, pid, out.ctypes.data_as(C.POINTER(C.c_uint8)), w))
+        return out
+
+    def fetch_source(self, index, channels=3):
+        """`input_image_np` (img2sgf.py:150) of image `index` of the last pass, after the on-device enhancement."""
+        h, w = self._last_shapes[index][:2]
+        out = np.empty((h, w, channels) if channels > 1 else (h, w), np.uint8)
+        self._check(self.lib.dll.i2s_fetch_source(self._ctx, index, out.ctypes.data_as(C.POINTER(C.c_uint8)), w * channels))
         return out
 
     def set_debug(self, on=True):

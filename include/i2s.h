@@ -16,6 +16,7 @@
  *   i2s_grid_from_lines   find_grid() 546-576 with injected circles and Hough-line rho lists
  *                         (what find_grid sees after find_lines 230-255 returned).
  *   i2s_choose_threshold  choose_threshold() 606-613.
+ *   i2s_fetch_source      input_image_np 150 after the on-device contrast / brightness step (141-149), if enabled.
  *   i2s_fetch_plane       the numpy images the GUI draws: grey_image_np 153,
  *                         edge_detected_image_np 162, the blur bank 171-175,
  *                         circles_removed_image_np 169-198.
@@ -107,6 +108,9 @@ typedef struct i2s_params {
     int32_t gauss_kernel_mode;         /* 0 = error-diffused taps summing to 256 | 1 = plain rounding */
     int32_t houghlines_numangle_mode;  /* 0 = floor+1 with pi-wrap fix (current) | 1 = cvRound (legacy) */
     int32_t inputs_on_device;          /* 1: img[] are device pointers (no copy); 0: host pointers */
+    /* Pillow pre-processing on the device (img2sgf.py:141-149): contrast / brightness slider values 0..100, the
+     * reference's defaults are 70 / 50.  -1 (default) = off: img[] already is `input_image_np` (:150). */
+    int32_t contrast, brightness;
 } i2s_params;
 
 /* Compact per-image record: what the SGF writer needs (to_SGF 781-810) and what ranks
@@ -181,6 +185,10 @@ int  i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int h,
 
 /* Copy one plane of image `index` of the last pass to host memory (dst: h rows of w bytes). */
 int  i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* dst, size_t dst_stride);
+
+/* Copy the (enhanced) source image of image `index` of the last pass: h rows of w * channels bytes.  Only available
+ * when the pass staged its inputs (host inputs, or contrast/brightness enabled). */
+int  i2s_fetch_source(i2s_ctx* ctx, int index, uint8_t* dst, size_t dst_stride);
 
 /* Stage timing of the last detect call, milliseconds measured with HIP events on the context's
  * stream: [0] blur+Canny (grey, 3 medians, 3 Gaussians, main Canny incl. hysteresis),

@@ -107,3 +107,17 @@ def test_errors(lib):
     with pytest.raises(I2sError):
         det.detect_batch([np.zeros((10, 10), np.uint8)], Params(hc_max_radius=40))
     det.close()
+
+
+def test_device_contrast_brightness_matches_pillow(lib):
+    """ImageEnhance.Contrast / .Brightness (img2sgf.py:141-149) on the device, from the raw decoded RGB."""
+    from img2sgf_amd import preprocess
+    for name, (c, b) in [("no_circles.jpg", (70, 50)), ("ex9.jpg", (70, 50)), ("ex9.jpg", (25, 85))]:
+        path = os.path.join(GOLDEN, "test_images", name)
+        raw = np.array(preprocess.load_image(path))
+        want = preprocess.enhance(preprocess.load_image(path), c, b)
+        det = Detector(0, 1, raw.shape[1], raw.shape[0], lib=lib)
+        d = det.detect_batch([raw], Params(contrast=c, brightness=b))[0]
+        np.testing.assert_array_equal(det.fetch_source(0), want)
+        parity.compare_detection(d, opipe.process_image(want))
+        det.close()

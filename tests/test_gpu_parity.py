@@ -188,3 +188,18 @@ def test_hysteresis_pass_budget_growth():
     det = Detector(0, 1, w, h)
     parity.run_and_compare(det, [img], internals=False)
     det.close()
+
+
+def test_device_contrast_brightness_all_fixtures():
+    """raw decoded RGB in, Pillow's contrast / brightness reproduced on the device (bit-exact), then the full path."""
+    from img2sgf_amd import preprocess
+    raws = [np.array(preprocess.load_image(os.path.join(GOLDEN, "test_images", n))) for n in IMAGES]
+    det = Detector(0, len(raws), max(i.shape[1] for i in raws), max(i.shape[0] for i in raws))
+    for (c, b) in [(70, 50), (40, 75)]:
+        boards = det.detect_batch(raws, Params(contrast=c, brightness=b), full=False)
+        for k, n in enumerate(IMAGES):
+            want = preprocess.enhance(preprocess.load_image(os.path.join(GOLDEN, "test_images", n)), c, b)
+            np.testing.assert_array_equal(det.fetch_source(k), want, err_msg=n)
+            if (c, b) == (70, 50):
+                assert board_to_sgf(boards[k]) == opipe.process_image(want, keep_planes=False)["sgf"], n
+    det.close()
