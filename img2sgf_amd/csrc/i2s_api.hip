@@ -44,7 +44,7 @@ struct i2s_ctx {
     int last_staged = 0;
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
-    int* d_weak = nullptr;       // [NMAP][nb][tiles] tile holds weak pixels
+    int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
     int* d_chg = nullptr;        // [NMAP][nb][tiles] last hysteresis pass (+1) that changed the tile
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
@@ -151,7 +151,7 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_lsum, nb * sizeof(unsigned long long)));
     I2S_HIP(hipMalloc(&ctx->d_tl_cnt, nb * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(unsigned short)));
-    I2S_HIP(hipMalloc(&ctx->d_weak, nb * NMAP * g.tiles * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_weak, 2 * (nb * NMAP * g.tiles + 1) * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_chg, nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
     ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
@@ -274,13 +274,15 @@ static GridParams grid_params(const i2s_params* p)
     return gp;
 }
 
-static int run_hysteresis(i2s_ctx* ctx, int phase, int m_first, int nmaps, int gx, int gy)
+static inline int* worklist(i2s_ctx* ctx, int phase) { return ctx->d_weak + (size_t)phase * ((size_t)ctx->max_batch * NMAP * ctx->geo.tiles + 1); }
+
+static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
 {
     int* flags = ctx->d_flags + (size_t)phase * HYST_MAX_PASSES;
-    const dim3 grid((unsigned)gx * gy * ctx->geo.nb * nmaps);
+    const int nblocks = max_tiles < HY_BLOCKS ? max_tiles : HY_BLOCKS;      // the worklist cannot be longer than max_tiles
     for (int pass = 0; pass < ctx->hyst_passes; pass++)
-        hipLaunchKernelGGL(k_hysteresis, grid, dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, plane_ptr(ctx, I2S_PLANE_CANNY_MAP),
-                           m_first, flags, pass, ctx->d_weak, ctx->d_chg, gx, gy);
+        hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, plane_ptr(ctx, I2S_PLANE_CANNY_MAP),
+                           flags, pass, worklist(ctx, phase), ctx->d_chg);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], flags + ctx->hyst_passes - 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
@@ -319,6 +321,8 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
         I2S_HIP(hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx), st));
         I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, 2 * HYST_MAX_PASSES * sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(worklist(ctx, 0), 0, sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(worklist(ctx, 1), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_chg, 0, (size_t)ctx->max_batch * NMAP * g.tiles * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
@@ -341,15 +345,15 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5, fx, fy);
         hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7, fx, fy);
         const int ngx = cdiv(fx, NMS_TPB);                             // groups of NMS_TPB tiles along x
-        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, ctx->d_weak, ngx, fy);
-        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, ctx->d_weak, fx, fy);
-        rc = run_hysteresis(ctx, 0, 0, 1, fx, fy);
+        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, worklist(ctx, 0), ngx, fy);
+        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
+        rc = run_hysteresis(ctx, 0, fx * fy * nb);
         if (rc) return rc;
         hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES), rx, ry);
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
         hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo,
-                           p->hc_param1, 0, ctx->d_weak, ngx, fy);
-        rc = run_hysteresis(ctx, 1, 1, NVAR, fx, fy);
+                           p->hc_param1, 0, worklist(ctx, 1), ngx, fy);
+        rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;
         hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
                            ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);

@@ -11,13 +11,14 @@ namespace i2s {
 constexpr int CT_W = 64;   // NMS output tile
 constexpr int CT_H = 32;
 constexpr int NMS_TPB = 4;  // consecutive tiles (along x) handled by one workgroup of k_sobel_nms_planes, software-pipelined
-// hysteresis works on the same 64 x 32 tiles; weak[(m * nb + b) * g.tiles + ty * g.tw + tx] != 0 iff the tile holds weak pixels
+// hysteresis works on the same 64 x 32 tiles.  Tiles that hold weak pixels are appended to a worklist by the NMS kernels:
+// wl[0] = count, wl[1 + i] = (m * nb + b) * g.tiles + ty * g.tw + tx; only those tiles are ever visited again.
 
 // Sobel + NMS of one tile.  src(y,x,c) = sp[y*sstride + x*CN + c].
 template <int CN>
 __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, int sstride, int w, int h,
-                                               int low, int high, uint8_t* __restrict__ mp, int mpitch, int* __restrict__ weak_flag,
-                                               int tile_x, int tile_y)
+                                               int low, int high, uint8_t* __restrict__ mp, int mpitch, int* __restrict__ weak_wl,
+                                               int weak_key, int tile_x, int tile_y)
 {
     __shared__ int s_weak;
     constexpr int SW = CT_W + 4, SH = CT_H + 4;   // source tile with 2-px apron
@@ -86,7 +87,7 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
         if (out == 0) s_weak = 1;
     }
     __syncthreads();
-    if (tid == 0) *weak_flag = s_weak;
+    if (tid == 0 && s_weak) weak_wl[1 + atomicAdd(&weak_wl[0], 1)] = weak_key;
 }
 
 // Main Canny (map 0) on the source image: grid (tiles_x, tiles_y, nb).
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict
     const ImgDesc im = desc[b];
     if (im.cn != CN) return;
     sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, g.pitch,
-                       weak + (size_t)b * g.tiles + (size_t)t.ty * g.tw + t.tx, t.tx, t.ty);
+                       weak, (int)((size_t)b * g.tiles + (size_t)t.ty * g.tw + t.tx), t.tx, t.ty);
 }
 
 // Sobel + NMS on single-channel PLANES, 4 pixels per thread with dword LDS traffic.
@@ -244,85 +245,97 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
         if (wk) s_weak = 1;
     }
     __syncthreads();
-    if (tid == 0) weak[((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x] = s_weak;
+    if (tid == 0 && s_weak)
+        weak[1 + atomicAdd(&weak[0], 1)] = (int)(((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x);
     }   // tiles of the group
 }
 
-// One hysteresis pass over maps [m_first, m_first + gridDim.z / nb).  Each block brings its 64x32 tile (with a read-only
-// 1-px apron) to a local fixed point in LDS.  The host launches passes back to back; a pass returns at once when the
-// previous pass changed nothing anywhere (flags[pass-1] == 0), a tile is skipped without touching memory when it holds
-// no weak pixel (flag written by the NMS kernel) or when neither it nor any of its 8 neighbours changed in the previous
+// One hysteresis pass over the tiles of a worklist (all maps of the phase).  A fixed, small grid of workgroups strides
+// over the list; each listed 64x32 tile (with a read-only 1-px apron) is brought to a local fixed point in LDS.  The host
+// launches passes back to back; a pass returns at once when the previous pass changed nothing anywhere
+// (flags[pass-1] == 0), and from pass 1 on a tile is revisited only if it or one of its 8 neighbours changed in the previous
 // pass (chg[tile] == index of the last pass that changed it, + 1).  The result is the unique fixed point of "a weak pixel
-// becomes an edge iff an 8-neighbour is an edge", independent of scheduling.
-// maps points at map 0; map m of image b at (m * nb + b) * slot.  grid (tiles_x, tiles_y, nb * nmaps), block 256.
+// becomes an edge iff an 8-neighbour is an edge", independent of scheduling and of the list order.
+// maps points at map 0; map m of image b at (m * nb + b) * slot.  grid (HY_BLOCKS), block 256.
+constexpr int HY_BLOCKS = 2048;
 __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
-                                                    int m_first, int* __restrict__ flags, int pass,
-                                                    const int* __restrict__ weak, int* __restrict__ chg, int gx, int gy)
+                                                    int* __restrict__ flags, int pass,
+                                                    const int* __restrict__ wl, int* __restrict__ chg)
 {
     constexpr int SROWS = CT_H + 2, SWORDS = CT_W / 4 + 2, SSTR = SWORDS + 1;    // bytes x0-4 .. x0+68, rows y0-1 .. y0+32
     __shared__ unsigned s_w[SROWS * SSTR];
     __shared__ int s_flag[2];
+    __shared__ int s_go;
     if (pass > 0 && flags[pass - 1] == 0) return;
-    const TileId tl = tile_of_block(gx, gy);
-    const int b = tl.z % g.nb;
-    const int m = m_first + tl.z / g.nb;
-    const int w = desc[b].w, h = desc[b].h;
-    const int x0 = tl.tx * CT_W, y0 = tl.ty * CT_H;
-    if (x0 >= w || y0 >= h) return;
-    const size_t tbase = ((size_t)m * g.nb + b) * g.tiles;
-    const int tile = tl.ty * g.tw + tl.tx;
-    if (weak[tbase + tile] == 0) return;
-    if (pass > 0) {
-        const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
-        bool any = false;
-        for (int dy = -1; dy <= 1; dy++)
-            for (int dx = -1; dx <= 1; dx++) {
-                const int tx = tl.tx + dx, ty = tl.ty + dy;
-                if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty && chg[tbase + ty * g.tw + tx] == pass) any = true;
-            }
-        if (!any) return;
-    }
-    uint8_t* mp = maps + ((size_t)m * g.nb + b) * g.slot;
+    const int nwl = wl[0];
     const int tid = threadIdx.x;
-    if (tid < 2) s_flag[tid] = 0;
-    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_ONE>(s_w, mp, g.pitch, w, h, x0 - 4, y0 - 1, tid);
-    __syncthreads();
-    uint8_t* s_map = reinterpret_cast<uint8_t*>(s_w);      // byte (row r, column c) at r * 4 * SSTR + c, pixel x0 + c - 4
-    constexpr int BSTR = 4 * SSTR;
-    // thread owns the 4 (wide) x 2 (tall) patch at tile rows py, py+1, byte columns px .. px+3
-    const int py = 1 + (tid / 16) * 2, px = 4 + (tid % 16) * 4;
-    bool any_change = false;
-    for (int iter = 0; iter < CT_W * CT_H; iter++) {
-        bool changed = false;
-        for (int dy = 0; dy < 2; dy++)
-            for (int dx = 0; dx < 4; dx++) {
-                const int o = (py + dy) * BSTR + px + dx;
-                if (s_map[o] != 0) continue;
-                if (s_map[o - BSTR - 1] == 2 || s_map[o - BSTR] == 2 || s_map[o - BSTR + 1] == 2 ||
-                    s_map[o - 1] == 2 || s_map[o + 1] == 2 ||
-                    s_map[o + BSTR - 1] == 2 || s_map[o + BSTR] == 2 || s_map[o + BSTR + 1] == 2) {
-                    s_map[o] = 2;
-                    changed = true;
-                }
+    for (int e = blockIdx.x; e < nwl; e += gridDim.x) {
+        const int key = wl[1 + e];
+        const int mb = key / g.tiles, tile = key - mb * g.tiles;       // mb = m * nb + b
+        const int b = mb % g.nb;
+        const int ty_ = tile / g.tw, tx_ = tile - ty_ * g.tw;
+        const int w = desc[b].w, h = desc[b].h;
+        const int x0 = tx_ * CT_W, y0 = ty_ * CT_H;
+        const size_t tbase = (size_t)mb * g.tiles;
+        if (pass > 0) {
+            // one thread decides (the stamps may be changing under us; the decision must be uniform across the workgroup
+            // because the tile body contains barriers)
+            __syncthreads();
+            if (tid == 0) {
+                const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
+                int any = 0;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int tx = tx_ + dx, ty = ty_ + dy;
+                        if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty && chg[tbase + ty * g.tw + tx] == pass) any = 1;
+                    }
+                s_go = any;
             }
-        if (changed) { s_flag[iter & 1] = 1; any_change = true; }
-        __syncthreads();
-        const int f = s_flag[iter & 1];
-        __syncthreads();
-        if (tid == 0) s_flag[iter & 1] = 0;
-        if (f == 0) break;
-    }
-    if (any_change) {
-        for (int dy = 0; dy < 2; dy++) {
-            const int gy = y0 + py + dy - 1;
-            if (gy >= h) continue;
-            const int gx = x0 + px - 4;
-            const unsigned v4 = s_w[(py + dy) * SSTR + px / 4];
-            if (gx + 3 < w) *reinterpret_cast<unsigned*>(mp + (size_t)gy * g.pitch + gx) = v4;
-            else for (int q = 0; q < 4 && gx + q < w; q++) mp[(size_t)gy * g.pitch + gx + q] = (uint8_t)(v4 >> (8 * q));
+            __syncthreads();
+            if (!s_go) continue;
         }
-        flags[pass] = 1;
-        chg[tbase + tile] = pass + 1;
+        uint8_t* mp = maps + (size_t)mb * g.slot;
+        __syncthreads();                                   // previous tile's LDS traffic is over
+        if (tid < 2) s_flag[tid] = 0;
+        load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_ONE>(s_w, mp, g.pitch, w, h, x0 - 4, y0 - 1, tid);
+        __syncthreads();
+        uint8_t* s_map = reinterpret_cast<uint8_t*>(s_w);      // byte (row r, column c) at r * 4 * SSTR + c, pixel x0 + c - 4
+        constexpr int BSTR = 4 * SSTR;
+        // thread owns the 4 (wide) x 2 (tall) patch at tile rows py, py+1, byte columns px .. px+3
+        const int py = 1 + (tid / 16) * 2, px = 4 + (tid % 16) * 4;
+        bool any_change = false;
+        for (int iter = 0; iter < CT_W * CT_H; iter++) {
+            bool changed = false;
+            for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 4; dx++) {
+                    const int o = (py + dy) * BSTR + px + dx;
+                    if (s_map[o] != 0) continue;
+                    if (s_map[o - BSTR - 1] == 2 || s_map[o - BSTR] == 2 || s_map[o - BSTR + 1] == 2 ||
+                        s_map[o - 1] == 2 || s_map[o + 1] == 2 ||
+                        s_map[o + BSTR - 1] == 2 || s_map[o + BSTR] == 2 || s_map[o + BSTR + 1] == 2) {
+                        s_map[o] = 2;
+                        changed = true;
+                    }
+                }
+            if (changed) { s_flag[iter & 1] = 1; any_change = true; }
+            __syncthreads();
+            const int f = s_flag[iter & 1];
+            __syncthreads();
+            if (tid == 0) s_flag[iter & 1] = 0;
+            if (f == 0) break;
+        }
+        if (any_change) {
+            for (int dy = 0; dy < 2; dy++) {
+                const int gy = y0 + py + dy - 1;
+                if (gy >= h) continue;
+                const int gx = x0 + px - 4;
+                const unsigned v4 = s_w[(py + dy) * SSTR + px / 4];
+                if (gx + 3 < w) *reinterpret_cast<unsigned*>(mp + (size_t)gy * g.pitch + gx) = v4;
+                else for (int q = 0; q < 4 && gx + q < w; q++) mp[(size_t)gy * g.pitch + gx + q] = (uint8_t)(v4 >> (8 * q));
+            }
+            flags[pass] = 1;
+            chg[tbase + tile] = pass + 1;
+        }
     }
 }
 
