@@ -138,7 +138,7 @@ def main():
                                    "device-resident, full hot path incl. board all-gather" % B,
                        "pass_size": pass_size, "streams": args.streams, "boards_match_generator": ok},
             "roofline": {"bound": "hbm",
-                         "kernel": "blur+Canny stage: k_grey, k_median3, k_median57, k_gauss<3,5,7>, k_sobel_nms_planes(main), "
+                         "kernel": "blur+Canny stage: k_grey, k_median3, k_median57, k_gauss357, k_sobel_nms_planes(main), "
                                    "k_hysteresis(map 0), k_edges_from_map",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,

@@ -341,9 +341,8 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
         hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                            plane_ptr(ctx, I2S_PLANE_MEDIAN7), mx, my);
-        hipLaunchKernelGGL((k_gauss<3>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3), t3, fx, fy);
-        hipLaunchKernelGGL((k_gauss<5>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS5), t5, fx, fy);
-        hipLaunchKernelGGL((k_gauss<7>), g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS7), t7, fx, fy);
+        hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3),
+                           plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
         const int ngx = cdiv(fx, NMS_TPB);                             // groups of NMS_TPB tiles along x
         if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, worklist(ctx, 0), ngx, fy);
         if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
@@ -374,7 +373,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL(k_line_peaks, dim3(nb), b256, 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
 
-        hipLaunchKernelGGL(k_grid, dim3(nb), b256, 0, st, ctx->d_desc, g, grey, gp, 1, ctx->d_res, ctx->d_boards);
+        hipLaunchKernelGGL(k_grid, dim3(nb), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, grey, gp, 1, ctx->d_res, ctx->d_boards);
         I2S_HIP(hipEventRecord(ctx->ev[4], st));
 
         I2S_HIP(hipMemcpyAsync(ctx->h_boards, ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToHost, st));
@@ -449,7 +448,7 @@ extern "C" int i2s_classify_batch(i2s_ctx* ctx, int first, int n, const i2s_para
     if (!ctx || !p || !boards || first < 0 || n < 1 || first + n > ctx->last_nb) return I2S_E_INVALID;
     I2S_HIP(hipSetDevice(ctx->device));
     const GridParams gp = grid_params(p);
-    hipLaunchKernelGGL(k_grid, dim3(n), dim3(256), 0, ctx->stream, ctx->d_desc + first, ctx->geo,
+    hipLaunchKernelGGL(k_grid, dim3(n), dim3(GRID_THREADS), 0, ctx->stream, ctx->d_desc + first, ctx->geo,
                        plane_ptr(ctx, I2S_PLANE_GREY) + (size_t)first * ctx->geo.slot, gp, 0, ctx->d_res + first, ctx->d_boards + first);
     I2S_HIP(hipMemcpyAsync(boards, ctx->d_boards + first, n * sizeof(i2s_board), hipMemcpyDeviceToHost, ctx->stream));
     if (full) I2S_HIP(hipMemcpyAsync(full, ctx->d_res + first, n * sizeof(i2s_result), hipMemcpyDeviceToHost, ctx->stream));
@@ -481,7 +480,7 @@ extern "C" int i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int
     hipError_t e1 = hipMemcpyAsync(ctx->d_desc, ctx->h_desc, sizeof(ImgDesc), hipMemcpyHostToDevice, st);
     hipError_t e2 = hipMemcpyAsync(ctx->d_res, hr, sizeof(i2s_result), hipMemcpyHostToDevice, st);
     hipError_t e3 = hipMemcpy2DAsync(plane_ptr(ctx, I2S_PLANE_GREY), g.pitch, grey, w, w, h, hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(k_grid, dim3(1), dim3(256), 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GREY), grid_params(p), 1,
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GREY), grid_params(p), 1,
                        ctx->d_res, ctx->d_boards);
     hipError_t e4 = hipMemcpyAsync(board, ctx->d_boards, sizeof(i2s_board), hipMemcpyDeviceToHost, st);
     hipError_t e5 = full ? hipMemcpyAsync(full, ctx->d_res, sizeof(i2s_result), hipMemcpyDeviceToHost, st) : hipSuccess;

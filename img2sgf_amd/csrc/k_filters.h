@@ -35,28 +35,22 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
     }
 }
 
-// ---- K3: separable fixed-point Gaussian, K in {3,5,7}.  4 pixels per thread, dword LDS traffic.
+// ---- K3: separable fixed-point Gaussians 3x3 (sigma 3), 5x5 (sigma 5), 7x7 (sigma 7) of the blur bank, one kernel:
+// the tile (+3 apron, BORDER_REFLECT_101) is fetched once and the three filters run back to back on it.
+// 4 pixels per thread, dword LDS traffic.
 // horizontal: t = sum w_i * p (<= 65280, 16 bit); vertical: a = sum w_j * t (32 bit); out = (a + 32768) >> 16.
+constexpr int GA_R = 3;                                                     // apron of the widest filter
+constexpr int GA_ROWS = FT_H + 2 * GA_R, GA_WORDS = FT_W / 4 + 2, GA_SSTR = GA_WORDS + 1;   // bytes x0-4 .. x0+68
+constexpr int GA_NS = FT_W / 4, GA_HSTR = 2 * GA_NS + 1;                    // u16 pairs per row
+
 template <int K>
-__global__ __launch_bounds__(256) void k_gauss(const ImgDesc* __restrict__ desc, Geo g,
-                                               const uint8_t* __restrict__ grey, uint8_t* __restrict__ out, Taps taps, int gx, int gy)
+__device__ __forceinline__ void gauss_on_tile(const unsigned* __restrict__ s_src, unsigned* __restrict__ s_h, const Taps& taps,
+                                              uint8_t* __restrict__ o, int pitch, int w, int h, int x0, int y0, int tid)
 {
-    constexpr int R = K / 2;
-    constexpr int SROWS = FT_H + 2 * R, SWORDS = FT_W / 4 + 2, SSTR = SWORDS + 1;   // bytes x0-4 .. x0+68
-    constexpr int NS = FT_W / 4, HSTR = 2 * NS + 1;                                 // u16 pairs per row
-    __shared__ unsigned s_src[SROWS * SSTR];
-    __shared__ unsigned s_h[SROWS * HSTR];
-    const TileId t = tile_of_block(gx, gy);
-    const int b = t.z;
-    const int w = desc[b].w, h = desc[b].h;
-    const int x0 = t.tx * FT_W, y0 = t.ty * FT_H;
-    if (x0 >= w || y0 >= h) return;
-    const int tid = threadIdx.x;
-    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_R101>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - R, tid);
-    __syncthreads();
-    for (int i = tid; i < SROWS * NS; i += 256) {
-        const int ry = i / NS, s = i - ry * NS;
-        const unsigned* ps = s_src + ry * SSTR + s;
+    constexpr int R = K / 2, ROWS = FT_H + 2 * R, ROW0 = GA_R - R;          // tile rows ROW0 .. ROW0 + ROWS - 1 are needed
+    for (int i = tid; i < ROWS * GA_NS; i += 256) {
+        const int ry = i / GA_NS, s = i - ry * GA_NS;
+        const unsigned* ps = s_src + (ROW0 + ry) * GA_SSTR + s;
         const unsigned wa = ps[0], wb = ps[1], wc = ps[2];
         int p[12];
 #pragma unroll
@@ -69,17 +63,16 @@ __global__ __launch_bounds__(256) void k_gauss(const ImgDesc* __restrict__ desc,
             for (int j = 0; j < K; j++) acc += (unsigned)taps.k[j] * (unsigned)p[4 + q - R + j];
             t[q] = acc > 65535u ? 65535u : acc;
         }
-        s_h[ry * HSTR + 2 * s] = t[0] | (t[1] << 16);
-        s_h[ry * HSTR + 2 * s + 1] = t[2] | (t[3] << 16);
+        s_h[ry * GA_HSTR + 2 * s] = t[0] | (t[1] << 16);
+        s_h[ry * GA_HSTR + 2 * s + 1] = t[2] | (t[3] << 16);
     }
     __syncthreads();
-    uint8_t* o = out + (size_t)b * g.slot;
-    for (int i = tid; i < FT_H * NS; i += 256) {
-        const int ly = i / NS, s = i - ly * NS;
+    for (int i = tid; i < FT_H * GA_NS; i += 256) {
+        const int ly = i / GA_NS, s = i - ly * GA_NS;
         unsigned a[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            const unsigned h0 = s_h[(ly + j) * HSTR + 2 * s], h1 = s_h[(ly + j) * HSTR + 2 * s + 1];
+            const unsigned h0 = s_h[(ly + j) * GA_HSTR + 2 * s], h1 = s_h[(ly + j) * GA_HSTR + 2 * s + 1];
             const unsigned tj = (unsigned)taps.k[j];
             a[0] += tj * (h0 & 0xffffu); a[1] += tj * (h0 >> 16); a[2] += tj * (h1 & 0xffffu); a[3] += tj * (h1 >> 16);
         }
@@ -88,11 +81,32 @@ __global__ __launch_bounds__(256) void k_gauss(const ImgDesc* __restrict__ desc,
         for (int q = 0; q < 4; q++) { const unsigned vv = (a[q] + 32768u) >> 16; ow |= (vv > 255u ? 255u : vv) << (8 * q); }
         const int x = x0 + 4 * s, y = y0 + ly;
         if (y < h && x < w) {
-            uint8_t* dp = o + (size_t)y * g.pitch + x;
+            uint8_t* dp = o + (size_t)y * pitch + x;
             if (x + 3 < w) *reinterpret_cast<unsigned*>(dp) = ow;
             else for (int q = 0; q < 4 && x + q < w; q++) dp[q] = (uint8_t)(ow >> (8 * q));
         }
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
+                                                  uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
+                                                  Taps t3, Taps t5, Taps t7, int gx, int gy)
+{
+    __shared__ unsigned s_src[GA_ROWS * GA_SSTR];
+    __shared__ unsigned s_h[GA_ROWS * GA_HSTR];
+    const TileId t = tile_of_block(gx, gy);
+    const int b = t.z;
+    const int w = desc[b].w, h = desc[b].h;
+    const int x0 = t.tx * FT_W, y0 = t.ty * FT_H;
+    if (x0 >= w || y0 >= h) return;
+    const int tid = threadIdx.x;
+    load_tile_words<GA_ROWS, GA_WORDS, GA_SSTR, 256, BORDER_R101>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - GA_R, tid);
+    __syncthreads();
+    const size_t off = (size_t)b * g.slot;
+    gauss_on_tile<3>(s_src, s_h, t3, out3 + off, g.pitch, w, h, x0, y0, tid);
+    gauss_on_tile<5>(s_src, s_h, t5, out5 + off, g.pitch, w, h, x0, y0, tid);
+    gauss_on_tile<7>(s_src, s_h, t7, out7 + off, g.pitch, w, h, x0, y0, tid);
 }
 
 // ---- K4: exact medians, BORDER_REPLICATE (cv.medianBlur, img2sgf.py:174).

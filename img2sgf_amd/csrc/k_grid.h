@@ -8,6 +8,8 @@
 
 namespace i2s {
 
+constexpr int GRID_THREADS = 1024;   // 16 wavefronts: the classifier sums 16 stone windows at a time
+
 struct GridParams {
     double min_grid_spacing, big_space_ratio;
     int black_threshold, align_x, align_y, pad;
@@ -87,7 +89,7 @@ __device__ __forceinline__ void cluster_axis(const float* __restrict__ rho, int 
                                              double* out, int* n_out)
 {
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += GRID_THREADS) {
         const float v = rho[i];
         int rank = 0;
         for (int j = 0; j < n; j++) { const float u = rho[j]; rank += (u < v || (u == v && j < i)) ? 1 : 0; }
@@ -114,10 +116,10 @@ __device__ __forceinline__ void cluster_axis(const float* __restrict__ rho, int 
     __syncthreads();
 }
 
-// grid (nb), block 256.  grey = variant plane 0.  Reads res[b].{circles, n_circles, hlines, vlines, status}
+// grid (nb), block GRID_THREADS.  grey = variant plane 0.  Reads res[b].{circles, n_circles, hlines, vlines, status}
 // and fills the rest of res[b] and boards[b].  do_cluster = 0 re-runs only identify_board on the stored grid
 // (apply_black_thresh, img2sgf.py:762-766).
-__global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
+__global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
                                               GridParams gp, int do_cluster, i2s_result* __restrict__ res,
                                               i2s_board* __restrict__ boards)
 {
@@ -193,16 +195,16 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
             s_i[5] = 0;
         }
         __syncthreads();
-        for (int i = tid; i < R->n_hcentres; i += 256) R->hcentres[i] = s_cen[0][i];
-        for (int i = tid; i < R->n_vcentres; i += 256) R->vcentres[i] = s_cen[1][i];
-        for (int i = tid; i < R->n_hcomplete; i += 256) R->hcentres_complete[i] = s_cmp[0][i];
-        for (int i = tid; i < R->n_vcomplete; i += 256) R->vcentres_complete[i] = s_cmp[1][i];
+        for (int i = tid; i < R->n_hcentres; i += GRID_THREADS) R->hcentres[i] = s_cen[0][i];
+        for (int i = tid; i < R->n_vcentres; i += GRID_THREADS) R->vcentres[i] = s_cen[1][i];
+        for (int i = tid; i < R->n_hcomplete; i += GRID_THREADS) R->hcentres_complete[i] = s_cmp[0][i];
+        for (int i = tid; i < R->n_vcomplete; i += GRID_THREADS) R->vcentres_complete[i] = s_cmp[1][i];
         {
             // radius filter (:443), all threads; a failed validation returns `circles` unfiltered (:426)
             const bool filt = s_i[4] != 0;
             const double lo = s_tmp[0][0], hi = s_tmp[0][1];
             int mine = 0;
-            for (int i = tid; i < R->n_circles; i += 256) {
+            for (int i = tid; i < R->n_circles; i += GRID_THREADS) {
                 int keep = 1;
                 if (filt) { const double r = (double)R->circles[i][2]; keep = (lo < r && r < hi) ? 1 : 0; }
                 R->circle_kept[i] = (uint8_t)keep;
@@ -215,17 +217,17 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
         __syncthreads();
     }
     if (!do_cluster) {
-        for (int i = tid; i < R->n_hcomplete; i += 256) s_cmp[0][i] = R->hcentres_complete[i];
-        for (int i = tid; i < R->n_vcomplete; i += 256) s_cmp[1][i] = R->vcentres_complete[i];
+        for (int i = tid; i < R->n_hcomplete; i += GRID_THREADS) s_cmp[0][i] = R->hcentres_complete[i];
+        for (int i = tid; i < R->n_vcomplete; i += GRID_THREADS) s_cmp[1][i] = R->vcentres_complete[i];
         __syncthreads();
     }
     // identify_board (:497-543)
     const bool ready = R->valid_grid && R->hsize <= I2S_BOARD_SIZE && R->vsize <= I2S_BOARD_SIZE && R->status != I2S_ST_CAPACITY;
     const int hsize = R->hsize, vsize = R->vsize;
-    for (int i = tid; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i += 256) (&s_det[0][0])[i] = 0;
+    for (int i = tid; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i += GRID_THREADS) (&s_det[0][0])[i] = 0;
     __syncthreads();
     if (ready) {
-        for (int i = tid; i < R->n_circles; i += 256) {
+        for (int i = tid; i < R->n_circles; i += GRID_THREADS) {
             if (!R->circle_kept[i]) continue;
             const int ci = closest_index((double)R->circles[i][0], s_cmp[1], hsize);
             const int cj = closest_index((double)R->circles[i][1], s_cmp[0], vsize);
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
     {
         const int wave = tid >> 6, lane = tid & 63;
         const uint8_t* gp0 = grey + (size_t)b * g.slot;
-        for (int s0 = 0; s0 < ns; s0 += 4) {
+        for (int s0 = 0; s0 < ns; s0 += GRID_THREADS / 64) {
             const int s = s0 + wave;
             unsigned sum = 0;
             int cnt = 0;
@@ -298,11 +300,11 @@ __global__ __launch_bounds__(256) void k_grid(const ImgDesc* __restrict__ desc, 
         s_i[3] = ready ? 1 : 0;
     }
     __syncthreads();
-    for (int i = tid; i < ns; i += 256) R->brightness[i] = s_br[i];
+    for (int i = tid; i < ns; i += GRID_THREADS) R->brightness[i] = s_br[i];
     // align_board (:484-494) + publish
     const int xoff = (gp.align_x == I2S_ALIGN_RIGHT) ? I2S_BOARD_SIZE - hsize : 0;
     const int yoff = (gp.align_y == I2S_ALIGN_BOTTOM) ? I2S_BOARD_SIZE - vsize : 0;
-    for (int i = tid; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i += 256) {
+    for (int i = tid; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i += GRID_THREADS) {
         const int bi = i / I2S_BOARD_SIZE, bj = i - bi * I2S_BOARD_SIZE;
         uint8_t v = 0;
         if (s_i[3]) {
