@@ -362,7 +362,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                            ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
                            ctx->d_est_keys, est_count(ctx));
-        hipLaunchKernelGGL(k_circles_final, dim3(nb * NVAR), b256, 0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx),
+        hipLaunchKernelGGL(k_circles_final, dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx),
                            p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));
 

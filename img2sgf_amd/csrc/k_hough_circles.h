@@ -384,10 +384,12 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
     }
 }
 
-// grid (nb * NVAR), block 256.  Sorts the estimates, runs RemoveOverlaps (greedy: keep a circle iff it is at
+constexpr int FIN_THREADS = 1024;
+
+// grid (nb * NVAR), block FIN_THREADS.  Sorts the estimates, runs RemoveOverlaps (greedy: keep a circle iff it is at
 // least min_dist from every circle already kept) and writes circles (x, y, r) in output order.
 // vcirc[(bv * VCIRC_CAP + i) * 3], vcount[bv]; overflow[b] is set when a capacity was exceeded.
-__global__ __launch_bounds__(256) void k_circles_final(Geo g, const unsigned long long* __restrict__ est_keys,
+__global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned long long* __restrict__ est_keys,
                                                        const int* __restrict__ est_count, const int* __restrict__ cent_count,
                                                        float min_dist, int min_r,
                                                        float* __restrict__ vcirc, int* __restrict__ vcount, int* __restrict__ overflow)
@@ -404,11 +406,11 @@ __global__ __launch_bounds__(256) void k_circles_final(Geo g, const unsigned lon
     }
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
-    for (int i = tid; i < np2; i += 256) s_key[i] = i < n ? est_keys[(size_t)bv * EST_CAP + i] : ~0ull;
+    for (int i = tid; i < np2; i += FIN_THREADS) s_key[i] = i < n ? est_keys[(size_t)bv * EST_CAP + i] : ~0ull;
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += 256) {
+            for (int i = tid; i < np2; i += FIN_THREADS) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long a = s_key[i], c = s_key[ixj];
