@@ -23,7 +23,7 @@ def test_shard_range_partitions():
 
 
 def test_two_rank_allgather(tmp_path):
-    total = 5          # uneven shards: 3 + 2
+    total = 3          # uneven shards: 2 + 1
     emu_util.emu_library()     # build once before the ranks race for it
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(total), str(tmp_path)],
