@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
 
 constexpr int FIN_THREADS = 1024;
 
-// grid (nb * NVAR), block FIN_THREADS.  Sorts the estimates, runs RemoveOverlaps (greedy: keep a circle iff it is at
-// least min_dist from every circle already kept) and writes circles (x, y, r) in output order.
+// grid (nb * NVAR), block FIN_THREADS.  Sorts the estimates (OpenCV's cmpAccum order), runs RemoveOverlaps (keep a circle
+// iff it is at least min_dist from every circle already kept) and writes circles (x, y, r) in output order.
 // vcirc[(bv * VCIRC_CAP + i) * 3], vcount[bv]; overflow[b] is set when a capacity was exceeded.
 __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned long long* __restrict__ est_keys,
                                                        const int* __restrict__ est_count, const int* __restrict__ cent_count,
@@ -395,7 +395,9 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
                                                        float* __restrict__ vcirc, int* __restrict__ vcount, int* __restrict__ overflow)
 {
     __shared__ unsigned long long s_key[EST_CAP];
-    __shared__ short s_kx[VCIRC_CAP], s_ky[VCIRC_CAP];
+    __shared__ short s_kx[VCIRC_CAP];
+    __shared__ int s_scan[FIN_THREADS];
+    __shared__ int s_flag;
     const int bv = blockIdx.x;
     const int b = bv / NVAR;
     const int tid = threadIdx.x;
@@ -420,38 +422,68 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
             }
             __syncthreads();
         }
-    // greedy min-dist pass by wavefront 0 (sequential over candidates, 64 kept circles per step)
-    if (tid < 64) {
-        const float md2 = min_dist * min_dist;
-        int kept = 0;
-        bool over = false;
-        for (int i = 0; i < n; i++) {
+    // RemoveOverlaps: circle i is kept iff no KEPT circle j < i lies within min_dist.  Resolved in parallel rounds instead
+    // of the sequential sweep: a candidate whose earlier neighbours (within min_dist) are all decided is decided itself;
+    // clusters around one stone settle in 2-3 rounds.  The outcome is the sequential greedy's, by induction on i.
+    unsigned char* s_st = reinterpret_cast<unsigned char*>(s_kx);        // 0 undecided, 1 kept, 2 rejected (n <= EST_CAP bytes)
+    static_assert(sizeof(short) * VCIRC_CAP >= EST_CAP, "status bytes alias s_kx");
+    for (int i = tid; i < n; i += FIN_THREADS) s_st[i] = 0;
+    __syncthreads();
+    const float md2 = min_dist * min_dist;
+    for (int round = 0; round < n; round++) {
+        bool undecided_left = false;
+        for (int i = tid; i < n; i += FIN_THREADS) {
+            if (s_st[i] != 0) continue;
             const unsigned long long key = s_key[i];
             const int x = (int)((key >> 16) & 0xffffu), y = (int)(key & 0xffffu);
-            bool bad = false;
-            for (int j0 = 0; j0 < kept; j0 += 64) {
-                const int j = j0 + tid;
-                bool hit = false;
-                if (j < kept) {
-                    const float ddx = (float)(x - s_kx[j]), ddy = (float)(y - s_ky[j]);
-                    hit = ddx * ddx + ddy * ddy < md2;
+            int verdict = 1;                                             // kept unless an earlier neighbour objects
+            for (int j = 0; j < i; j++) {
+                const unsigned long long kj = s_key[j];
+                const float ddx = (float)(x - (int)((kj >> 16) & 0xffffu)), ddy = (float)(y - (int)(kj & 0xffffu));
+                if (ddx * ddx + ddy * ddy < md2) {
+                    const int sj = s_st[j];
+                    if (sj == 1) { verdict = 2; break; }
+                    if (sj == 0) verdict = 0;                            // must wait for j
                 }
-                if (__ballot(hit) != 0ull) { bad = true; break; }
             }
-            if (!bad) {
-                if (kept >= VCIRC_CAP) { over = true; break; }
-                if (tid == 0) {
-                    s_kx[kept] = (short)x; s_ky[kept] = (short)y;
-                    const int s = 1023 - (int)((key >> 32) & 0x3ffu);
-                    float* o = vcirc + ((size_t)bv * VCIRC_CAP + kept) * 3;
-                    o[0] = ((float)x + 0.5f) * 1.0f;
-                    o[1] = ((float)y + 0.5f) * 1.0f;
-                    o[2] = (float)s / 2.f / 10.f * 1.0f + (float)min_r;
-                }
-                kept++;
-            }
+            if (verdict) s_st[i] = (unsigned char)verdict; else undecided_left = true;
         }
-        if (tid == 0) { vcount[bv] = over ? 0 : kept; if (over) overflow[b] = 1; }
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        if (undecided_left) s_flag = 1;
+        __syncthreads();
+        if (s_flag == 0) break;
+    }
+    // ordered compaction of the kept circles (block-wide inclusive scan over chunks of FIN_THREADS candidates)
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += FIN_THREADS) {
+        const int i = c0 + tid;
+        const int keep = (i < n && s_st[i] == 1) ? 1 : 0;
+        s_scan[tid] = keep;
+        __syncthreads();
+        for (int d = 1; d < FIN_THREADS; d <<= 1) {
+            const int v = tid >= d ? s_scan[tid - d] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int pos = base + s_scan[tid] - keep;
+        if (keep && pos < VCIRC_CAP) {
+            const unsigned long long key = s_key[i];
+            const int x = (int)((key >> 16) & 0xffffu), y = (int)(key & 0xffffu);
+            const int sr = 1023 - (int)((key >> 32) & 0x3ffu);
+            float* o = vcirc + ((size_t)bv * VCIRC_CAP + pos) * 3;
+            o[0] = ((float)x + 0.5f) * 1.0f;
+            o[1] = ((float)y + 0.5f) * 1.0f;
+            o[2] = (float)sr / 2.f / 10.f * 1.0f + (float)min_r;
+        }
+        base += s_scan[FIN_THREADS - 1];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool over = base > VCIRC_CAP;
+        vcount[bv] = over ? 0 : base;
+        if (over) overflow[b] = 1;
     }
 }
 
