@@ -158,15 +158,20 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
     // counts come from one lane-indexed load.  Bins are handed out dynamically (LDS ticket) because their populations
     // differ a lot (grid lines concentrate in a few bins): with a static split the waves of a workgroup spent 40 % of
     // their time waiting for the slowest one at the barrier.  Each wave keeps one bin in flight ahead of the one it walks.
-    int my_cnt = 0;
-    if (lane < nbin) my_cnt = bin_cnt[bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx)];
+    // lane q computes bin q's index once (the division by the window width is the expensive part); the walk fetches it
+    // with v_readlane
+    int my_cnt = 0, my_bin = 0;
+    if (lane < nbin) {
+        my_bin = (int)(bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx));
+        my_cnt = bin_cnt[my_bin];
+    }
     int q = wave;                                   // first round: bin == wave index, later rounds: ticket
     int n_cur = 0;
     const uint2* ent_cur = bin_ent;
     uint2 mine = make_uint2(0u, 0u);
     if (q < nbin) {
         n_cur = __builtin_amdgcn_readlane(my_cnt, q);
-        ent_cur = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+        ent_cur = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, q) * EB_CAP;
         if (lane < n_cur) mine = ent_cur[lane];
     }
     while (q < nbin) {
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
         uint2 mine_next = make_uint2(0u, 0u);
         if (qn < nbin) {
             n_next = __builtin_amdgcn_readlane(my_cnt, qn);
-            ent_next = bin_ent + (bin_base + (size_t)(by0 + qn / nbx) * g.bw + (bx0 + qn % nbx)) * EB_CAP;
+            ent_next = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, qn) * EB_CAP;
             if (lane < n_next) mine_next = ent_next[lane];
         }
         for (int k0 = 0; k0 < n_cur; k0 += 64) {
@@ -267,7 +272,7 @@ __device__ __forceinline__ unsigned long long est_key(int acc, int s, int x, int
 constexpr int RAD_BINS_MAX = 320;   // 5 x 64
 
 // Radius estimate + support check of every centre candidate (hough.cpp HoughCircleEstimateRadiusInvoker).
-// grid (RAD_GX, nb * NVAR), block 256 = 4 wavefronts, one centre per wavefront per round.
+// grid (RAD_GX, nb * NVAR), block 256 = 4 independent wavefronts, one centre per wavefront at a time.
 // The voting edge pixels near the centre come from the edge bins (the same set OpenCV keeps in `nz`); their distances
 // go into a 10-bins-per-pixel LDS histogram; the histogram scan (windows of 10 bins opened at every non-empty bin,
 // walking down from the largest radius) runs wave-uniformly on prefix sums + 64-bit occupancy masks.
@@ -290,11 +295,12 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
     const float minR2 = (float)min_r * (float)min_r, maxR2 = (float)max_r * (float)max_r;
     const size_t bin_base = (size_t)bv * g.bins;
     int* bins = s_bins[wave];
-    for (int c0 = blockIdx.x * 4; c0 < n; c0 += gridDim.x * 4) {
-        const int c = c0 + wave;
-        const bool live = c < n;
+    // every wavefront works through its centres on its own: the phases below are separated by wave-level barriers only
+    // (LDS operations of one wave complete in order), so the four waves of a workgroup never wait for each other
+    for (int c = blockIdx.x * 4 + wave; c < n; c += gridDim.x * 4) {
+        const bool live = true;
         for (int i = lane; i < RAD_BINS_MAX; i += 64) bins[i] = 0;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         int cxi = 0, cyi = 0;
         if (live) {
             const unsigned e = cent_list[(size_t)bv * CENT_CAP + c];
@@ -305,8 +311,11 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
             const int bx0 = imax(cxi - max_r, 0) / EB, bx1 = imin(cxi + max_r + 1, w - 1) / EB;
             const int by0 = imax(cyi - max_r, 0) / EB, by1 = imin(cyi + max_r + 1, h - 1) / EB;
             const int nbx = bx1 - bx0 + 1, nbin = nbx * (by1 - by0 + 1);        // <= 9
-            int my_cnt = 0;
-            if (lane < nbin) my_cnt = bin_cnt[bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx)];
+            int my_cnt = 0, my_bin = 0;
+            if (lane < nbin) {
+                my_bin = (int)(bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx));
+                my_cnt = bin_cnt[my_bin];
+            }
             unsigned pre[9];
             int cnt[9];
 #pragma unroll
@@ -314,14 +323,14 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
                 pre[q] = 0xffffffffu; cnt[q] = 0;
                 if (q < nbin) {
                     cnt[q] = __builtin_amdgcn_readlane(my_cnt, q);
-                    const uint2* ent = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+                    const uint2* ent = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, q) * EB_CAP;
                     if (lane < cnt[q]) pre[q] = ent[lane].x;
                 }
             }
 #pragma unroll
             for (int q = 0; q < 9; q++) {
                 if (q >= nbin) continue;
-                const uint2* ent = bin_ent + (bin_base + (size_t)(by0 + q / nbx) * g.bw + (bx0 + q % nbx)) * EB_CAP;
+                const uint2* ent = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, q) * EB_CAP;
                 for (int k = lane; k < cnt[q]; k += 64) {
                     const unsigned xy = k < 64 ? pre[q] : ent[k].x;
                     const float ddx = cx - (float)(int)(xy & 0xffffu), ddy = cy - (float)(int)(xy >> 16);
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         // inclusive prefix sums P[i] (in place) and occupancy masks, 64 bins per step
         unsigned long long occ[RAD_BINS_MAX / 64];
         int carry = 0;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
             carry = __shfl(vsum, 63);
             bins[q * 64 + lane] = vsum;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (live) {
             int maxCount = 0, sBest = 0;
             float rBest = 0.f;
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
                 if (k < EST_CAP) est_keys[(size_t)bv * EST_CAP + k] = est_key(imin(maxCount, 4095), sBest, cxi, cyi);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -100,6 +100,8 @@ template <class T> static inline T __shfl_down(T v, unsigned d) { return __shfl(
 template <class T> static inline T __shfl_xor(T v, int m) { return __shfl(v, hipemu::cur->lane ^ m); }
 // wave-uniform lane select (v_readlane_b32): all live lanes call it with the same lane index
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
+// wave-level barrier: on hardware only a scheduling barrier (a wave runs in lockstep); here all live lanes rendezvous
+static inline void __builtin_amdgcn_wave_barrier() { unsigned long long a[64], m; hipemu::wave_exchange(0, a, &m); }
 static inline int __lane_id() { return hipemu::cur->lane; }
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
