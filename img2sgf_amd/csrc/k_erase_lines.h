@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     __shared__ int s_n;
     __shared__ int s_hist[LROWS][LB];
     __shared__ int s_rmin[LROWS];
+    __shared__ unsigned short s_nz[ET_W * ET_H];
+    __shared__ float s_cos[LROWS], s_sin[LROWS];
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z;
     const int w = desc[b].w, h = desc[b].h;
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
             }
         }
         s_rmin[tid] = rmin;
+        s_cos[tid] = n < trig.n[c] ? trig.cos_[c][n] : 0.f;
+        s_sin[tid] = n < trig.n[c] ? trig.sin_[c][n] : 0.f;
     }
     int best[8];
 #pragma unroll
@@ -134,15 +138,17 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         }
         __syncthreads();
         const int n = s_n;
-        if (n > 0) {
+        {
+            // this thread's 8 pixels share one column (x0 + (tid & 63)) and lie on rows y0 + (tid >> 6) + 4k
+            const int px = x0 + (tid & (ET_W - 1)), py0 = y0 + (tid >> 6);
+            for (int j = 0; j < n; j++) {
+                if (px < s_box[j][0] || px > s_box[j][1]) continue;
+                const int by0 = s_box[j][2], by1 = s_box[j][3], idx = s_idx[j];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int p = tid + k * 256;
-                const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
-                int bst = best[k];
-                for (int j = 0; j < n; j++)
-                    if (px >= s_box[j][0] && px <= s_box[j][1] && py >= s_box[j][2] && py <= s_box[j][3]) bst = imax(bst, s_idx[j]);
-                best[k] = bst;
+                for (int k = 0; k < 8; k++) {
+                    const int py = py0 + 4 * k;
+                    if (py >= by0 && py <= by1) best[k] = imax(best[k], idx);
+                }
             }
         }
         __syncthreads();
@@ -150,6 +156,8 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     if (ncand == 0) __syncthreads();   // s_hist / s_rmin initialisation
     const uint8_t* e = edges + (size_t)b * g.slot;
     uint8_t* o = removed + (size_t)b * g.slot;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int p = tid + k * 256;
@@ -164,16 +172,27 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
             val = e[(size_t)py * g.pitch + px];
         }
         o[(size_t)py * g.pitch + px] = val;
-        if (val != 0) {
-            for (int c = 0; c < 3; c++)
-                for (int n = 0; n < trig.n[c]; n++) {
-                    const float a = (float)px * trig.cos_[c][n], bb = (float)py * trig.sin_[c][n];
-                    const int r = __float2int_rn(a + bb);
-                    const int row = c * LANG + n;
-                    const unsigned bin = (unsigned)(r - s_rmin[row]);
-                    if (bin < (unsigned)LB) atomicAdd(&s_hist[row][bin], 1);
-                    else atomicAdd(&lacc[((size_t)b * LROWS + row) * lrow + r + half], 1);
-                }
+        if (val != 0) s_nz[atomicAdd(&s_n, 1)] = (unsigned short)p;      // non-zero pixels are few: vote on a dense list
+    }
+    __syncthreads();
+    {
+        const int nnz = s_n;
+        int nang = 0, rows_of[LROWS];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            for (int n = 0; n < trig.n[c]; n++) rows_of[nang++] = c * LANG + n;
+        for (int it = tid; it < nnz * nang; it += 256) {
+            const int pi = it / nang, ai = it - pi * nang;
+            const int p = s_nz[pi];
+            const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
+            int row = rows_of[0];
+#pragma unroll
+            for (int q = 1; q < LROWS; q++) if (q == ai) row = rows_of[q];
+            const float a = (float)px * s_cos[row], bb = (float)py * s_sin[row];
+            const int r = __float2int_rn(a + bb);
+            const unsigned bin = (unsigned)(r - s_rmin[row]);
+            if (bin < (unsigned)LB) atomicAdd(&s_hist[row][bin], 1);
+            else atomicAdd(&lacc[((size_t)b * LROWS + row) * lrow + r + half], 1);
         }
     }
     __syncthreads();
