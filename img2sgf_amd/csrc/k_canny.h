@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     constexpr int MROWS = CT_H + 2, MSTRIPS = CT_W / 4 + 2, MSTR = 2 * MSTRIPS + 1;   // mag rows y0-1.., x0-4 .. x0+68 (u16 pairs)
     __shared__ unsigned s_src[SROWS * SSTR];
     __shared__ unsigned s_mag[MROWS * MSTR];
+    __shared__ unsigned s_grad[CT_H * (CT_W / 4) * 4];      // dx01, dx23, dy01, dy23 of the core strips
     // gx counts GROUPS of NMS_TPB tiles; the workgroup walks its group left to right and fetches tile t+1 into registers
     // while it computes tile t (the tile kernels are otherwise latency-bound: load -> wait -> compute -> store)
     const TileId tl = tile_of_block(gx, gy);
@@ -143,13 +144,12 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry.
     // Two pixels per register (16-bit lanes, v_pk_* instructions): column sums / row differences of the 3x6
     // neighbourhood, then dx = col[+1] - col[-1], dy = dif[-1] + 2 dif[0] + dif[+1], mag = |dx| + |dy|.
-    constexpr int NSTRIPS = MROWS * MSTRIPS;          // 34 * 18 = 612
+    constexpr int NSTRIPS = MROWS * MSTRIPS;          // 34 * 18 = 612 gradient strips (core + apron)
     constexpr int PER = (NSTRIPS + 255) / 256;        // 3
-    v2s gdx01[PER], gdx23[PER], gdy01[PER], gdy23[PER], gm01[PER], gm23[PER];
+    constexpr int NCORE = CT_H * (CT_W / 4);          // 512 core strips: exactly 2 per thread in the NMS phase
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int i = tid + k * 256;
-        gdx01[k] = gdx23[k] = gdy01[k] = gdy23[k] = gm01[k] = gm23[k] = pk_from(0u);
         if (i < NSTRIPS) {
             const int ry = i / MSTRIPS, s = i - ry * MSTRIPS;
             const unsigned* p0 = s_src + ry * SSTR + s;
@@ -180,24 +180,28 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
                 dx23 = pk_from(pk_bits(dx23) & k23); dy23 = pk_from(pk_bits(dy23) & k23);
             }
             const v2s mg01 = pk_abs(dx01) + pk_abs(dy01), mg23 = pk_abs(dx23) + pk_abs(dy23);
-            gdx01[k] = dx01; gdx23[k] = dx23; gdy01[k] = dy01; gdy23[k] = dy23; gm01[k] = mg01; gm23[k] = mg23;
             s_mag[ry * MSTR + 2 * s] = pk_bits(mg01);
             s_mag[ry * MSTR + 2 * s + 1] = pk_bits(mg23);
+            if (ry >= 1 && ry <= CT_H && s >= 1 && s <= CT_W / 4) {
+                // core strip: park the gradient for the NMS phase, which is mapped densely onto the 512 core strips
+                unsigned* pg = s_grad + ((ry - 1) * (CT_W / 4) + (s - 1)) * 4;
+                pg[0] = pk_bits(dx01); pg[1] = pk_bits(dx23); pg[2] = pk_bits(dy01); pg[3] = pk_bits(dy23);
+            }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int i = tid + k * 256;
-        if (i >= NSTRIPS) continue;
-        const int ry = i / MSTRIPS, s = i - ry * MSTRIPS;
-        if (ry < 1 || ry > CT_H || s < 1 || s > CT_W / 4) continue;      // apron strips only feed neighbours
+    for (int k = 0; k < NCORE / 256; k++) {
+        const int ci = tid + k * 256;
+        const int ry = ci / (CT_W / 4) + 1, s = ci % (CT_W / 4) + 1;
         const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
         if (gy >= h || gx0 >= w) continue;
         unsigned outw = 0x01010101u;
-        const unsigned mb01 = pk_bits(gm01[k]), mb23 = pk_bits(gm23[k]);
+        const unsigned mb01 = s_mag[ry * MSTR + 2 * s], mb23 = s_mag[ry * MSTR + 2 * s + 1];
         const int mxall = imax(imax((int)(mb01 & 0xffffu), (int)(mb01 >> 16)), imax((int)(mb23 & 0xffffu), (int)(mb23 >> 16)));
         if (mxall > low) {
+            const unsigned* pg = s_grad + ci * 4;
+            const unsigned gxb[2] = {pg[0], pg[1]}, gyb[2] = {pg[2], pg[3]};
             // magnitudes of rows ry-1, ry, ry+1 at columns -1 .. 4 of the strip
             int mg[3][6];
 #pragma unroll
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
             for (int q = 0; q < 4; q++) {
                 // branch-free NMS: evaluate the three sector rules and select (divergent branches cost more than the ALU work)
                 const int mcur = mg[1][q + 1];
-                const unsigned xb = pk_bits(q < 2 ? gdx01[k] : gdx23[k]), yb = pk_bits(q < 2 ? gdy01[k] : gdy23[k]);
+                const unsigned xb = gxb[q >> 1], yb = gyb[q >> 1];
                 const int xs = (q & 1) ? ((int)xb >> 16) : (int)(short)(xb & 0xffffu);
                 const int ys = (q & 1) ? ((int)yb >> 16) : (int)(short)(yb & 0xffffu);
                 const int ax = iabs_(xs), ay = iabs_(ys) << 15;
