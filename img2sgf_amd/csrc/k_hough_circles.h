@@ -248,9 +248,6 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
     // of an accumulator whose votes sit at unpadded indices; cells x == W or y == H hold no votes).
     // tile cell (cx, cy): 16-bit half (cy >> 6) of dword (cy & 63) * VASTR + cx
 #define I2S_CELL(cx, cy) ((int)((s_acc[((cy) & 63) * VASTR + (cx)] >> (((cy) >> 6) * 16)) & 0xffffu))
-#ifdef I2S_EXP_NOCENTRE
-    if (cent_count != nullptr) return;
-#endif
     if (dbg_acc) {
         for (int i = tid; i < VT * VT; i += VTHREADS) {
             const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
