@@ -282,7 +282,7 @@ static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
     const int nblocks = max_tiles < HY_BLOCKS ? max_tiles : HY_BLOCKS;      // the worklist cannot be longer than max_tiles
     for (int pass = 0; pass < ctx->hyst_passes; pass++)
         hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, plane_ptr(ctx, I2S_PLANE_CANNY_MAP),
-                           flags, pass, worklist(ctx, phase), ctx->d_chg);
+                           phase == 0 ? plane_ptr(ctx, I2S_PLANE_EDGES) : (uint8_t*)nullptr, flags, pass, worklist(ctx, phase), ctx->d_chg);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], flags + ctx->hyst_passes - 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
@@ -327,6 +327,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
         uint8_t* map0 = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
+        uint8_t* edges = plane_ptr(ctx, I2S_PLANE_EDGES);
         const dim3 b64x4(64, 4), b256(256);
         // tile grids of this pass (1-D launches, XCD-aware tile order inside the kernels)
         const int rx = cdiv(wmax, 256), ry = cdiv(hmax, 4);            // row kernels: 256 x 4 pixels per workgroup
@@ -344,14 +345,22 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3),
                            plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
         const int ngx = cdiv(fx, NMS_TPB);                             // groups of NMS_TPB tiles along x
-        if (has_c1) hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, 0, p->canny_lo, p->canny_hi, 1, worklist(ctx, 0), ngx, fy);
-        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
+        // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
+        // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
+        const bool fused0 = has_c1 && p->canny_lo == hc_lo;
+        if (fused0)
+            hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
+                               p->hc_param1, p->canny_hi, 2, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
+        else if (has_c1)
+            hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
+                               p->canny_lo, p->canny_hi, p->canny_hi, 1, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
+        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
         rc = run_hysteresis(ctx, 0, fx * fy * nb);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_edges_from_map, g_row, b64x4, 0, st, ctx->d_desc, g, map0, plane_ptr(ctx, I2S_PLANE_EDGES), rx, ry);
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
-        hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0, 0, hc_lo,
-                           p->hc_param1, 0, worklist(ctx, 1), ngx, fy);
+        const int v_first = fused0 ? 1 : 0;
+        hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb * (NVAR - v_first)), b256, 0, st, ctx->d_desc, g, grey, map0,
+                           (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, 0, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;
         hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,

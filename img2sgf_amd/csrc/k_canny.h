@@ -17,8 +17,8 @@ constexpr int NMS_TPB = 4;  // consecutive tiles (along x) handled by one workgr
 // Sobel + NMS of one tile.  src(y,x,c) = sp[y*sstride + x*CN + c].
 template <int CN>
 __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, int sstride, int w, int h,
-                                               int low, int high, uint8_t* __restrict__ mp, int mpitch, int* __restrict__ weak_wl,
-                                               int weak_key, int tile_x, int tile_y)
+                                               int low, int high, uint8_t* __restrict__ mp, uint8_t* __restrict__ ep, int mpitch,
+                                               int* __restrict__ weak_wl, int weak_key, int tile_x, int tile_y)
 {
     __shared__ int s_weak;
     constexpr int SW = CT_W + 4, SH = CT_H + 4;   // source tile with 2-px apron
@@ -84,6 +84,7 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
             if (keep) out = (m > high) ? 2 : 0;
         }
         mp[(size_t)gy * mpitch + gx] = out;
+        ep[(size_t)gy * mpitch + gx] = out == 2 ? 255 : 0;      // the edge image (img2sgf.py:162); hysteresis adds the promoted pixels
         if (out == 0) s_weak = 1;
     }
     __syncthreads();
@@ -93,27 +94,34 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
 // Main Canny (map 0) on the source image: grid (tiles_x, tiles_y, nb).
 template <int CN>
 __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ map0,
-                                                       int low, int high, int* __restrict__ weak, int gx, int gy)
+                                                       uint8_t* __restrict__ edges, int low, int high, int* __restrict__ weak,
+                                                       int gx, int gy)
 {
     const TileId t = tile_of_block(gx, gy);
     const int b = t.z;
     const ImgDesc im = desc[b];
     if (im.cn != CN) return;
-    sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, g.pitch,
+    sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, edges + (size_t)b * g.slot, g.pitch,
                        weak, (int)((size_t)b * g.tiles + (size_t)t.ty * g.tw + t.tx), t.tx, t.ty);
 }
 
 // Sobel + NMS on single-channel PLANES, 4 pixels per thread with dword LDS traffic.
 //   main_mode == 0: HoughCircles' internal Canny of variants [v_first, v_first + gridDim.z / nb): plane v -> map 1 + v.
 //   main_mode == 1: the main Canny (img2sgf.py:162) of greyscale sources: plane 0 (grey == source) -> map 0
-//                   (colour sources go through k_sobel_nms_src<3>).
+//                   (colour sources go through k_sobel_nms_src<3>); also writes the edge image (255 where the map says
+//                   "edge") into `edges`, which the map-0 hysteresis then completes.
+//   main_mode == 2: both at once for variant 0 (the grey plane): HoughCircles' Canny (low, high) -> map 1 and, for greyscale
+//                   sources, the main Canny (low, high_main) -> map 0 + edges.  Valid when both use the same low threshold
+//                   (the reference's 50 == 100 / 2): the gradients, sectors and suppression decisions are then shared and
+//                   only the strong / weak split differs.
 // grid (tiles_x, tiles_y, nb * nvariants), block 256, tile 64 x 32 outputs.
 // planes = variant plane 0 base, maps = map 0 base.
 __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
-                                                          uint8_t* __restrict__ maps, int v_first, int low, int high, int main_mode,
-                                                          int* __restrict__ weak, int gx, int gy)
+                                                          uint8_t* __restrict__ maps, uint8_t* __restrict__ edges, int v_first, int low,
+                                                          int high, int high_main, int main_mode, int* __restrict__ weak,
+                                                          int* __restrict__ weak_main, int gx, int gy)
 {
-    __shared__ int s_weak;
+    __shared__ int s_weak, s_weak0;
     constexpr int SROWS = CT_H + 4, SWORDS = CT_W / 4 + 4, SSTR = SWORDS + 1;   // source rows y0-2.., x0-8 .. x0+72
     constexpr int MROWS = CT_H + 2, MSTRIPS = CT_W / 4 + 2, MSTR = 2 * MSTRIPS + 1;   // mag rows y0-1.., x0-4 .. x0+68 (u16 pairs)
     __shared__ unsigned s_src[SROWS * SSTR];
@@ -124,20 +132,27 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z % g.nb;
     const int v = main_mode ? 0 : v_first + tl.z / g.nb;
-    if (main_mode && desc[b].cn != 1) return;
+    if (main_mode == 1 && desc[b].cn != 1) return;
+    const bool main_out = main_mode != 0 && desc[b].cn == 1;     // writes map 0 + edges
+    if (main_mode == 1) high = high_main;
     const int w = desc[b].w, h = desc[b].h;
     const int y0 = tl.ty * CT_H;
     if (tl.tx * NMS_TPB * CT_W >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const uint8_t* plane = planes + ((size_t)v * g.nb + b) * g.slot;
-    uint8_t* mp = maps + ((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.slot;
+    // first output: the variant's map (modes 0, 2) or map 0 (mode 1); second output (mode 2 only): map 0
+    const int m_first = main_mode == 1 ? 0 : 1 + v;
+    uint8_t* mp = maps + ((size_t)m_first * g.nb + b) * g.slot;
+    uint8_t* mp0 = (main_mode == 2 && main_out) ? maps + (size_t)b * g.slot : nullptr;
+    uint8_t* ep = main_out ? edges + (size_t)b * g.slot : nullptr;
+    int* weak_first = main_mode == 1 ? weak_main : weak;
     TileRegs<SROWS, SWORDS, 256, BORDER_REPL> pre;
     pre.fetch(plane, g.pitch, w, h, tl.tx * NMS_TPB * CT_W - 8, y0 - 2, tid);
     for (int tt = 0; tt < NMS_TPB; tt++) {
     const int tile_x = tl.tx * NMS_TPB + tt;
     const int x0 = tile_x * CT_W;
     if (x0 >= w) break;
-    if (tid == 0) s_weak = 0;
+    if (tid == 0) { s_weak = 0; s_weak0 = 0; }
     pre.park<SSTR>(s_src, tid);
     __syncthreads();
     if (tt + 1 < NMS_TPB && x0 + CT_W < w) pre.fetch(plane, g.pitch, w, h, x0 + CT_W - 8, y0 - 2, tid);
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
         const int ry = ci / (CT_W / 4) + 1, s = ci % (CT_W / 4) + 1;
         const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
         if (gy >= h || gx0 >= w) continue;
-        unsigned outw = 0x01010101u;
+        unsigned outw = 0x01010101u, outw0 = 0x01010101u;
         const unsigned mb01 = s_mag[ry * MSTR + 2 * s], mb23 = s_mag[ry * MSTR + 2 * s + 1];
         const int mxall = imax(imax((int)(mb01 & 0xffffu), (int)(mb01 >> 16)), imax((int)(mb23 & 0xffffu), (int)(mb23 >> 16)));
         if (mxall > low) {
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
                 mg[rr][0] = (int)(a >> 16); mg[rr][1] = (int)(b0 & 0xffffu); mg[rr][2] = (int)(b0 >> 16);
                 mg[rr][3] = (int)(b1 & 0xffffu); mg[rr][4] = (int)(b1 >> 16); mg[rr][5] = (int)(c & 0xffffu);
             }
-            outw = 0;
+            outw = 0; outw0 = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 // branch-free NMS: evaluate the three sector rules and select (divergent branches cost more than the ALU work)
@@ -233,24 +248,39 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
                 const int d_b = dr ^ ((dr ^ dl) & msk);
                 const int c_d = (mcur > d_a) & (mcur > d_b);
                 const int keep = (ay < tg22x) ? c_h : ((ay > tg67x) ? c_v : c_d);
-                const unsigned o = ((mcur > low) & keep) ? ((mcur > high) ? 2u : 0u) : 1u;
+                const int kept = (mcur > low) & keep;
+                const unsigned o = kept ? ((mcur > high) ? 2u : 0u) : 1u;
+                const unsigned o0 = kept ? ((mcur > high_main) ? 2u : 0u) : 1u;
                 outw |= o << (8 * q);
+                outw0 |= o0 << (8 * q);
             }
         }
-        uint8_t* dstp = mp + (size_t)gy * g.pitch + gx0;
-        bool wk;
+        const size_t off = (size_t)gy * g.pitch + gx0;
+        const unsigned outm = mp0 ? outw0 : outw;                        // the word that is the main Canny's map
+        const unsigned edgw = ((outm >> 1) & 0x01010101u) * 0xffu;       // 255 where that byte is 2
+        bool wk, wk0 = false;
         if (gx0 + 3 < w) {
-            *reinterpret_cast<unsigned*>(dstp) = outw;
+            *reinterpret_cast<unsigned*>(mp + off) = outw;
+            if (mp0) *reinterpret_cast<unsigned*>(mp0 + off) = outw0;
+            if (ep) *reinterpret_cast<unsigned*>(ep + off) = edgw;
             wk = ((outw - 0x01010101u) & ~outw & 0x80808080u) != 0;      // some byte == 0
+            if (mp0) wk0 = ((outw0 - 0x01010101u) & ~outw0 & 0x80808080u) != 0;
         } else {
             wk = false;
-            for (int q = 0; q < 4 && gx0 + q < w; q++) { dstp[q] = (uint8_t)(outw >> (8 * q)); wk |= ((outw >> (8 * q)) & 0xffu) == 0; }
+            for (int q = 0; q < 4 && gx0 + q < w; q++) {
+                mp[off + q] = (uint8_t)(outw >> (8 * q)); wk |= ((outw >> (8 * q)) & 0xffu) == 0;
+                if (mp0) { mp0[off + q] = (uint8_t)(outw0 >> (8 * q)); wk0 |= ((outw0 >> (8 * q)) & 0xffu) == 0; }
+                if (ep) ep[off + q] = (uint8_t)(edgw >> (8 * q));
+            }
         }
+        if (wk0) s_weak0 = 1;
         if (wk) s_weak = 1;
     }
     __syncthreads();
     if (tid == 0 && s_weak)
-        weak[1 + atomicAdd(&weak[0], 1)] = (int)(((size_t)(main_mode ? 0 : 1 + v) * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x);
+        weak_first[1 + atomicAdd(&weak_first[0], 1)] = (int)(((size_t)m_first * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x);
+    if (tid == 0 && s_weak0)
+        weak_main[1 + atomicAdd(&weak_main[0], 1)] = (int)((size_t)b * g.tiles + (size_t)tl.ty * g.tw + tile_x);
     }   // tiles of the group
 }
 
@@ -260,10 +290,12 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
 // (flags[pass-1] == 0), and from pass 1 on a tile is revisited only if it or one of its 8 neighbours changed in the previous
 // pass (chg[tile] == index of the last pass that changed it, + 1).  The result is the unique fixed point of "a weak pixel
 // becomes an edge iff an 8-neighbour is an edge", independent of scheduling and of the list order.
-// maps points at map 0; map m of image b at (m * nb + b) * slot.  grid (HY_BLOCKS), block 256.
+// maps points at map 0; map m of image b at (m * nb + b) * slot.  `edges` (non-null for the main Canny's phase, whose worklist
+// holds map-0 tiles only) receives 255 / 0 for every rewritten tile: together with the NMS kernel's output that is the edge
+// image of img2sgf.py:162.  grid (HY_BLOCKS), block 256.
 constexpr int HY_BLOCKS = 2048;
 __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
-                                                    int* __restrict__ flags, int pass,
+                                                    uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
                                                     const int* __restrict__ wl, int* __restrict__ chg)
 {
     constexpr int SROWS = CT_H + 2, SWORDS = CT_W / 4 + 2, SSTR = SWORDS + 1;    // bytes x0-4 .. x0+68, rows y0-1 .. y0+32
@@ -334,30 +366,19 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
                 if (gy >= h) continue;
                 const int gx = x0 + px - 4;
                 const unsigned v4 = s_w[(py + dy) * SSTR + px / 4];
-                if (gx + 3 < w) *reinterpret_cast<unsigned*>(mp + (size_t)gy * g.pitch + gx) = v4;
-                else for (int q = 0; q < 4 && gx + q < w; q++) mp[(size_t)gy * g.pitch + gx + q] = (uint8_t)(v4 >> (8 * q));
+                const unsigned e4 = ((v4 >> 1) & 0x01010101u) * 0xffu;
+                uint8_t* ep = edges ? edges + (size_t)mb * g.slot : nullptr;      // mb == b in the main phase
+                if (gx + 3 < w) {
+                    *reinterpret_cast<unsigned*>(mp + (size_t)gy * g.pitch + gx) = v4;
+                    if (ep) *reinterpret_cast<unsigned*>(ep + (size_t)gy * g.pitch + gx) = e4;
+                } else for (int q = 0; q < 4 && gx + q < w; q++) {
+                    mp[(size_t)gy * g.pitch + gx + q] = (uint8_t)(v4 >> (8 * q));
+                    if (ep) ep[(size_t)gy * g.pitch + gx + q] = (uint8_t)(e4 >> (8 * q));
+                }
             }
             flags[pass] = 1;
             chg[tbase + tile] = pass + 1;
         }
-    }
-}
-
-// edges = 255 where map0 == 2 else 0 (img2sgf.py:162 output; also variant plane 1 and the erase target).
-__global__ __launch_bounds__(256) void k_edges_from_map(const ImgDesc* __restrict__ desc, Geo g,
-                                                        const uint8_t* __restrict__ map0, uint8_t* __restrict__ edges, int gx, int gy)
-{
-    const TileId t = tile_of_block(gx, gy);
-    const int b = t.z;
-    const int w = desc[b].w, h = desc[b].h;
-    const int y = t.ty * 4 + threadIdx.y;
-    const int x0 = (t.tx * 64 + threadIdx.x) * 4;
-    if (y >= h || x0 >= w) return;
-    const uint8_t* mp = map0 + (size_t)b * g.slot + (size_t)y * g.pitch;
-    uint8_t* e = edges + (size_t)b * g.slot + (size_t)y * g.pitch;
-    for (int i = 0; i < 4; i++) {
-        const int x = x0 + i;
-        if (x < w) e[x] = mp[x] == 2 ? 255 : 0;
     }
 }
 

@@ -287,6 +287,7 @@ __device__ __forceinline__ unsigned long long est_key(int acc, int s, int x, int
 }
 
 constexpr int RAD_BINS_MAX = 320;   // 5 x 64
+constexpr int RAD_LUT = 512;        // radius-bin table: K / 2 < max_r^2 / 2 <= 450 (max_r <= 30, checked by the host)
 
 // Radius estimate + support check of every centre candidate (hough.cpp HoughCircleEstimateRadiusInvoker).
 // grid (RAD_GX, nb * NVAR), block 256 = 4 independent wavefronts, one centre per wavefront at a time.
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
                                                 unsigned long long* __restrict__ est_keys, int* __restrict__ est_count)
 {
     __shared__ int s_bins[4][RAD_BINS_MAX];
+    __shared__ unsigned short s_lut[RAD_LUT];
     const int bv = blockIdx.y;
     const int b = bv / NVAR;
     const int w = desc[b].w, h = desc[b].h;
@@ -309,7 +311,17 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
     const int nBinsPerDr = 10;
     int nBins = __float2int_rn((float)(max_r - min_r) / 1.0f * (float)nBinsPerDr);
     if (nBins < 1) nBins = 1;
-    const float minR2 = (float)min_r * (float)min_r, maxR2 = (float)max_r * (float)max_r;
+    if (blockIdx.x * 4 >= n) return;
+    // The centre is (cxi + 0.5, cyi + 0.5) and edge pixels are integers, so the squared distance OpenCV computes in float is
+    // exactly K + 0.5 with K = dx (dx + 1) + dy (dy + 1), an even integer: the radius bin is a function of K / 2 alone.  The
+    // table holds OpenCV's own float expression evaluated once per K; minR^2 <= K + 0.5 <= maxR^2  <=>  min_r^2 <= K < max_r^2.
+    const int k_lo = min_r * min_r, k_hi = max_r * max_r;
+    for (int i = threadIdx.x; i < RAD_LUT; i += 256) {
+        const float d = sqrtf((float)(2 * i) + 0.5f);
+        const int bi = __float2int_rn((d - (float)min_r) / 1.0f * (float)nBinsPerDr);
+        s_lut[i] = (unsigned short)imax(0, imin(nBins - 1, bi));
+    }
+    __syncthreads();
     const size_t bin_base = (size_t)bv * g.bins;
     int* bins = s_bins[wave];
     // every wavefront works through its centres on its own: the phases below are separated by wave-level barriers only
@@ -322,7 +334,6 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
         if (live) {
             const unsigned e = cent_list[(size_t)bv * CENT_CAP + c];
             cxi = (int)(e & 0xffffu); cyi = (int)(e >> 16);
-            const float cx = ((float)cxi + 0.5f) * 1.0f, cy = ((float)cyi + 0.5f) * 1.0f;
             // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: at most 3 x 3 bins overlap that box.
             // Lane q fetches bin q's count, then all record loads of all bins are issued before any is consumed.
             const int bx0 = imax(cxi - max_r, 0) / EB, bx1 = imin(cxi + max_r + 1, w - 1) / EB;
@@ -350,35 +361,32 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
                 const uint2* ent = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, q) * EB_CAP;
                 for (int k = lane; k < cnt[q]; k += 64) {
                     const unsigned xy = k < 64 ? pre[q] : ent[k].x;
-                    const float ddx = cx - (float)(int)(xy & 0xffffu), ddy = cy - (float)(int)(xy >> 16);
-                    const float r2 = ddx * ddx + ddy * ddy;
-                    if (minR2 <= r2 && r2 <= maxR2) {
-                        const float d = sqrtf(r2);
-                        int bi = __float2int_rn((d - (float)min_r) / 1.0f * (float)nBinsPerDr);
-                        bi = imax(0, imin(nBins - 1, bi));
-                        atomicAdd(&bins[bi], 1);
-                    }
+                    const int dxi = cxi - (int)(xy & 0xffffu), dyi = cyi - (int)(xy >> 16);
+                    const int K = __mul24(dxi, dxi + 1) + __mul24(dyi, dyi + 1);
+                    if (K >= k_lo && K < k_hi) atomicAdd(&bins[s_lut[K >> 1]], 1);
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // inclusive prefix sums P[i] (in place) and occupancy masks, 64 bins per step
+        // occupancy masks (64 bins per ballot), then inclusive prefix sums P[i] in place: every lane owns 5 consecutive bins, so
+        // one wave scan of the per-lane totals suffices
         unsigned long long occ[RAD_BINS_MAX / 64];
-        int carry = 0;
 #pragma unroll
-        for (int q = 0; q < RAD_BINS_MAX / 64; q++) {
-            const int vraw = bins[q * 64 + lane];
-            occ[q] = __ballot(vraw != 0);
-            int vsum = vraw;
+        for (int q = 0; q < RAD_BINS_MAX / 64; q++) occ[q] = __ballot(bins[q * 64 + lane] != 0);
+        __builtin_amdgcn_wave_barrier();
+        constexpr int PERL = RAD_BINS_MAX / 64;
+        int loc[PERL];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl(vsum, lane >= d ? lane - d : lane);
-                if (lane >= d) vsum += t;
-            }
-            vsum += carry;
-            carry = __shfl(vsum, 63);
-            bins[q * 64 + lane] = vsum;
+        for (int q = 0; q < PERL; q++) loc[q] = bins[lane * PERL + q] + (q ? loc[q - 1] : 0);
+        int vsum = loc[PERL - 1];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl(vsum, lane >= d ? lane - d : lane);
+            if (lane >= d) vsum += t;
         }
+        const int excl = vsum - loc[PERL - 1];
+#pragma unroll
+        for (int q = 0; q < PERL; q++) bins[lane * PERL + q] = loc[q] + excl;
         __builtin_amdgcn_wave_barrier();
         if (live) {
             int maxCount = 0, sBest = 0;

@@ -36,7 +36,7 @@ def blur_bank(grey, edges, compat):
 
 
 def process_image(img, threshold=None, black_thr=128, alignment=(glue.LEFT, glue.TOP),
-                  compat=None, keep_planes=True):
+                  compat=None, keep_planes=True, canny=(50, 200)):
     """img: HxW (grey) or HxWx3 (RGB as the reference holds it) uint8, i.e. the array
     `input_image_np` of img2sgf.py:150.  Returns a dict with every value the reference
     leaves in its globals after process_image()/find_grid()."""
@@ -47,7 +47,7 @@ def process_image(img, threshold=None, black_thr=128, alignment=(glue.LEFT, glue
         threshold = glue.choose_threshold(W, H)
     out = dict(threshold=threshold)
     grey = cvo.bgr2gray(img, compat["grey_shift"])                     # :153
-    edges = cvo.canny(img, 50, 200)                                    # :162
+    edges = cvo.canny(img, canny[0], canny[1])                         # :162 (50, 200 in the reference)
     blurs = blur_bank(grey, edges, compat)                             # :171-175
     per_variant = []
     circles = np.zeros((0, 3), np.float32)

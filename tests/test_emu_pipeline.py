@@ -47,6 +47,19 @@ def test_reference_fixture(lib, name):
     det.close()
 
 
+def test_mixed_colour_batch_and_unfused_canny(lib):
+    """A greyscale and a colour source in one device pass (the fused grey-plane Canny handles the first, the colour kernel
+    the second), then the same batch with a main-Canny low threshold that differs from HoughCircles' (separate passes)."""
+    a = synth.synth_diagram(3, geom=synth.GEOM_SMALL)[0]
+    rng = np.random.default_rng(11)
+    col = np.stack([a, np.clip(a.astype(int) + rng.integers(-40, 40, a.shape), 0, 255).astype(np.uint8), a[::-1]], axis=-1)
+    det = Detector(0, 2, a.shape[1], a.shape[0], lib=lib)
+    parity.run_and_compare(det, [a, np.ascontiguousarray(col)], internals=True)
+    parity.run_and_compare(det, [a, np.ascontiguousarray(col)], params=Params(canny_lo=40, canny_hi=150),
+                           oracle_kwargs=dict(canny=(40, 150)))
+    det.close()
+
+
 def test_tiny_images(lib):
     det = Detector(0, 4, 70, 70, lib=lib)
     rng = np.random.default_rng(5)

@@ -33,6 +33,20 @@ def test_small_synthetic_with_internals():
     det.close()
 
 
+def test_mixed_colour_batch_and_unfused_canny():
+    """Greyscale + colour sources in one device pass (fused grey-plane Canny / colour Canny side by side), then a main-Canny
+    low threshold that differs from HoughCircles' (the two Cannys of the grey plane run as separate passes)."""
+    a = synth.synth_diagram(3, geom=synth.GEOM_SMALL)[0]
+    rng = np.random.default_rng(11)
+    col = np.ascontiguousarray(np.stack(
+        [a, np.clip(a.astype(int) + rng.integers(-40, 40, a.shape), 0, 255).astype(np.uint8), a[::-1]], axis=-1))
+    det = Detector(0, 2, a.shape[1], a.shape[0])
+    parity.run_and_compare(det, [a, col], internals=True)
+    parity.run_and_compare(det, [a, col], params=Params(canny_lo=40, canny_hi=150), oracle_kwargs=dict(canny=(40, 150)))
+    parity.run_and_compare(det, [col, a, col], params=Params(canny_lo=50, canny_hi=120), oracle_kwargs=dict(canny=(50, 120)))
+    det.close()
+
+
 def test_tiny_and_ragged():
     det = Detector(0, 8, 330, 300)      # one device pass, so every image's planes are still resident for the comparison
     rng = np.random.default_rng(5)
