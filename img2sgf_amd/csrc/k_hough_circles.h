@@ -19,6 +19,7 @@ constexpr int VASTR = 129;       // dword row stride of the LDS tile (odd: verti
 constexpr int VTHREADS = 512;
 constexpr int EB = 32;           // edge bins: EB x EB pixel cells
 constexpr int EB_CAP = EB * EB;  // worst case: every pixel of a bin is an edge
+constexpr int EBB_X = 4, EBB_Y = 2;   // bins per k_edge_bins workgroup (128 x 64 pixels)
 
 // Sobel 3x3 with BORDER_REPLICATE at one pixel of a single-channel plane.
 __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitch, int w, int h, int x, int y, int& dx, int& dy)
@@ -38,37 +39,45 @@ __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitc
 //   .x = x | y << 16,  .y = (sx & 0xffff) | sy << 16
 // with (sx, sy) = cvRound(d * 1024 / |d|) of its Sobel gradient d (hough.cpp HoughCirclesAccumInvoker), stored in the
 // bin of its 32x32-pixel cell.  The vote kernel then streams only the bins within reach of its accumulator tile.
-// grid (ceil(bins_x / 4), bins_y, nb * NVAR), block 256 (16 pixels per thread).
+// grid (ceil(bins_x / EBB_X) * ceil(bins_y / EBB_Y) * nb * NVAR), block 256 (32 pixels per thread).
 // bin_cnt[(bv * g.bins) + by * g.bw + bx], bin_ent[... * EB_CAP + k].
 __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ desc, Geo g,
                                                    const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
                                                    uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt, int gx, int gy)
 {
-    // one block = 4 horizontally adjacent bins (128 x 32 pixels); one 16-byte map load per thread.  Edge positions are
-    // first compacted into an LDS list so that the gradient work (8 neighbour loads, sqrt, 2 divides) is spread evenly
-    // over the block instead of serialising inside the few threads whose 16 pixels lie on a line.
-    __shared__ unsigned s_list[4 * EB * EB];
+    // one block = 4 x 2 bins (128 x 64 pixels); two 16-byte map loads per thread, both in flight together (the kernel is
+    // latency-bound: load -> compact -> gather -> store).  Edge positions are first compacted into an LDS list (13-bit
+    // tile-local coordinates) so that the gradient work (8 neighbour loads, sqrt, 2 divides) is spread evenly over the
+    // block instead of serialising inside the few threads whose pixels lie on a line.
+    __shared__ unsigned short s_list[EBB_X * EBB_Y * EB * EB];
     __shared__ int s_nl;
-    __shared__ int s_n[4];
+    __shared__ int s_n[EBB_X * EBB_Y];
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z / NVAR, v = tl.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
-    const int x0 = tl.tx * (4 * EB), y0 = tl.ty * EB;
+    const int x0 = tl.tx * (EBB_X * EB), y0 = tl.ty * (EBB_Y * EB);
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const size_t off = ((size_t)v * g.nb + b) * g.slot;
     const uint8_t* plane = planes + off;
     const uint8_t* map = maps + off;
-    const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)tl.ty * g.bw + (size_t)tl.tx * 4;
-    if (tid < 4) s_n[tid] = 0;
-    if (tid == 4) s_nl = 0;
+    const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)tl.ty * EBB_Y * g.bw + (size_t)tl.tx * EBB_X;
+    if (tid < EBB_X * EBB_Y) s_n[tid] = 0;
+    if (tid == 32) s_nl = 0;
     __syncthreads();
     {
         const int ly = tid >> 3, c16 = (tid & 7) * 16;
-        const int y = y0 + ly, xs = x0 + c16;
-        if (y < h && xs < w) {
-            const uint4 m16 = *reinterpret_cast<const uint4*>(map + (size_t)y * g.pitch + xs);
-            const unsigned mw[4] = {m16.x, m16.y, m16.z, m16.w};
+        const int xs = x0 + c16;
+        uint4 m16[EBB_Y];
+#pragma unroll
+        for (int r = 0; r < EBB_Y; r++) {
+            const int y = y0 + ly + r * EB;
+            m16[r] = make_uint4(0u, 0u, 0u, 0u);
+            if (y < h && xs < w) m16[r] = *reinterpret_cast<const uint4*>(map + (size_t)y * g.pitch + xs);
+        }
+#pragma unroll
+        for (int r = 0; r < EBB_Y; r++) {
+            const unsigned mw[4] = {m16[r].x, m16[r].y, m16[r].z, m16[r].w};
 #pragma unroll
             for (int d = 0; d < 4; d++) {
                 const unsigned m4 = mw[d];
@@ -76,8 +85,9 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
                 if (((t - 0x01010101u) & ~t & 0x80808080u) == 0) continue;      // no byte == 2
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int x = xs + 4 * d + q;
-                    if (x < w && ((m4 >> (8 * q)) & 0xffu) == 2u) s_list[atomicAdd(&s_nl, 1)] = (unsigned)x | ((unsigned)y << 16);
+                    const int lx = c16 + 4 * d + q;
+                    if (x0 + lx < w && ((m4 >> (8 * q)) & 0xffu) == 2u)
+                        s_list[atomicAdd(&s_nl, 1)] = (unsigned short)(lx | ((ly + r * EB) << 7));
                 }
             }
         }
@@ -85,8 +95,9 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     __syncthreads();
     const int nl = s_nl;
     for (int i = tid; i < nl; i += 256) {
-        const unsigned e = s_list[i];
-        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+        const int le = s_list[i];
+        const int lx = le & 127, lyy = le >> 7;
+        const int x = x0 + lx, y = y0 + lyy;
         int dx, dy;
         sobel_at(plane, g.pitch, w, h, x, y, dx, dy);
         if (dx == 0 && dy == 0) continue;
@@ -95,12 +106,16 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
         if (mag < 1.0f) continue;
         const int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
         const int sy = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
-        const int kb = (x - x0) / EB;
-        const int k = atomicAdd(&s_n[kb], 1);
-        bin_ent[(bin0 + kb) * EB_CAP + k] = make_uint2(e, ((unsigned)sx & 0xffffu) | ((unsigned)sy << 16));
+        const int kbx = lx / EB, kby = lyy / EB;
+        const int k = atomicAdd(&s_n[kby * EBB_X + kbx], 1);
+        bin_ent[(bin0 + (size_t)kby * g.bw + kbx) * EB_CAP + k] =
+            make_uint2((unsigned)x | ((unsigned)y << 16), ((unsigned)sx & 0xffffu) | ((unsigned)sy << 16));
     }
     __syncthreads();
-    if (tid < 4 && x0 + tid * EB < w) bin_cnt[bin0 + tid] = s_n[tid];
+    if (tid < EBB_X * EBB_Y) {
+        const int kbx = tid % EBB_X, kby = tid / EBB_X;
+        if (x0 + kbx * EB < w && y0 + kby * EB < h) bin_cnt[bin0 + (size_t)kby * g.bw + kbx] = s_n[tid];
+    }
 }
 
 // Votes of up to 32 edge records held in a per-wave LDS ring.  Lane l handles record l & 31 in direction l >> 5 and steps
