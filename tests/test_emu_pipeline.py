@@ -60,6 +60,12 @@ def test_mixed_colour_batch_and_unfused_canny(lib):
     det.close()
 
 
+def test_noisy_small_synthetic(lib):
+    det = Detector(0, 1, 300, 260, lib=lib)
+    parity.run_and_compare(det, [synth.synth_diagram(4, noisy=True, geom=synth.GEOM_SMALL)[0]], internals=True)
+    det.close()
+
+
 def test_tiny_images(lib):
     det = Detector(0, 4, 70, 70, lib=lib)
     rng = np.random.default_rng(5)

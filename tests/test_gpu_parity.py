@@ -69,6 +69,15 @@ def test_synthetic_1024_with_internals():
     det.close()
 
 
+def test_noisy_synthetic_1024_with_internals():
+    """BASELINE configs[1] "noisy" variant (N(0, 6^2) noise): many more weak edges, long hysteresis chains, dense vote
+    accumulators -- every plane, accumulator, circle and line must still match the oracle."""
+    det = Detector(0, 2, 1024, 1024)
+    imgs = [synth.synth_diagram(s, noisy=True)[0] for s in (0, 1)]
+    parity.run_and_compare(det, imgs, internals=True)
+    det.close()
+
+
 def test_synthetic_1024_batch_multi_pass():
     det = Detector(0, 4, 1024, 1024)
     imgs, occs = synth.synth_batch(range(100, 110))
