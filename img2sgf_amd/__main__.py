@@ -19,6 +19,8 @@ def main(argv=None):
     ap.add_argument("-o", "--outdir", help="directory for <name>.sgf when several inputs are given")
     ap.add_argument("--contrast", type=int, default=preprocess.CONTRAST_DEFAULT)
     ap.add_argument("--brightness", type=int, default=preprocess.BRIGHTNESS_DEFAULT)
+    ap.add_argument("--rotate", type=float, default=0.0, help="rotation angle in degrees (the reference's rotate slider)")
+    ap.add_argument("--selection", type=int, nargs=4, metavar=("X1", "Y1", "X2", "Y2"), help="region to process (default: whole image)")
     ap.add_argument("--threshold", type=int, default=0, help="Hough-lines threshold (0 = choose_threshold)")
     ap.add_argument("--black-threshold", type=int, default=128)
     ap.add_argument("--device", type=int, default=0)
@@ -27,12 +29,17 @@ def main(argv=None):
     if len(inputs) == 2 and inputs[1].lower().endswith(".sgf") and not args.outdir:
         inputs, out_single = inputs[:1], inputs[1]
     import numpy as np
-    images = [np.array(preprocess.load_image(p)) for p in inputs]        # decoded RGB; contrast / brightness run on the GPU
-    det = pipeline.Detector(args.device, min(len(images), 16), max(i.shape[1] for i in images), max(i.shape[0] for i in images))
+    images = [np.array(preprocess.load_image(p)) for p in inputs]   # decoded RGB; rotate / crop / contrast / brightness run on the GPU
+    xforms = None
+    if args.rotate != 0 or args.selection:
+        xforms = [preprocess.xform((i.shape[1], i.shape[0]), args.rotate, args.selection) for i in images]
+    out_w = [x[1][2] - x[1][0] for x in xforms] if xforms else [i.shape[1] for i in images]
+    out_h = [x[1][3] - x[1][1] for x in xforms] if xforms else [i.shape[0] for i in images]
+    det = pipeline.Detector(args.device, min(len(images), 16), max(out_w), max(out_h))
     params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
                              contrast=args.contrast, brightness=args.brightness)
     rc = 0
-    for path, d in zip(inputs, det.detect_batch(images, params)):
+    for path, d in zip(inputs, det.detect_batch(images, params, xforms=xforms)):
         name = os.path.splitext(os.path.basename(path))[0] + ".sgf"
         out = out_single or (os.path.join(args.outdir, name) if args.outdir else None)
         if not d.board_ready:

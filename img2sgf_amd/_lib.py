@@ -75,11 +75,16 @@ class I2sResult(C.Structure):
     ]
 
 
+class I2sXform(C.Structure):
+    """i2s_xform: Pillow's inverse affine matrix of Image.rotate() + the crop box (crop_and_rotate_image, img2sgf.py:110-114)."""
+    _fields_ = [("affine", C.c_double * 6), ("crop", C.c_int32 * 4)]
+
+
 assert C.sizeof(I2sBoard) == 384
 assert C.sizeof(I2sResult) == 73384
 
 EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
-           "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_classify_batch", "i2s_grid_from_lines",
+           "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_classify_batch", "i2s_grid_from_lines",
            "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc"]
 
 
@@ -114,6 +119,8 @@ class I2sLibrary:
         L.i2s_destroy.restype = None
         L.i2s_detect_batch.argtypes = [vp, C.c_int, C.POINTER(vp), ip, ip, ip, ip, C.POINTER(I2sParams),
                                        C.POINTER(I2sBoard), C.POINTER(I2sResult)]
+        L.i2s_detect_batch_xf.argtypes = [vp, C.c_int, C.POINTER(vp), ip, ip, ip, ip, C.POINTER(I2sXform),
+                                          C.POINTER(I2sParams), C.POINTER(I2sBoard), C.POINTER(I2sResult)]
         L.i2s_classify_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(I2sParams), C.POINTER(I2sBoard),
                                          C.POINTER(I2sResult)]
         L.i2s_grid_from_lines.argtypes = [vp, u8p, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int,

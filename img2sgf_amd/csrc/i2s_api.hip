@@ -42,6 +42,10 @@ struct i2s_ctx {
     float* d_vcirc = nullptr;
     unsigned long long* d_lsum = nullptr;   // [nb] luma sums for the contrast step
     int last_staged = 0;
+    XfDesc* d_xf = nullptr;      // [max_batch] pre-transform descriptors (i2s_detect_batch_xf)
+    XfDesc* h_xf = nullptr;
+    uint8_t* d_raw = nullptr;    // untransformed host sources of one pass (grown on demand)
+    size_t raw_bytes = 0;
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
     int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
@@ -121,9 +125,9 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum, ctx->d_xf, ctx->d_raw};
     for (void* q : dev) if (q) (void)hipFree(q);
-    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards};
+    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf};
     for (void* q : host) if (q) (void)hipHostFree(q);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -158,6 +162,8 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_src, nb * ctx->src_slot + 256));
     I2S_HIP(hipMalloc(&ctx->d_desc, nb * sizeof(ImgDesc)));
     I2S_HIP(hipHostMalloc(&ctx->h_desc, nb * sizeof(ImgDesc)));
+    I2S_HIP(hipMalloc(&ctx->d_xf, nb * sizeof(XfDesc)));
+    I2S_HIP(hipHostMalloc(&ctx->h_xf, nb * sizeof(XfDesc)));
     I2S_HIP(hipMalloc(&ctx->d_flags, 2 * HYST_MAX_PASSES * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_flags, 2 * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * CENT_CAP * sizeof(unsigned)));
@@ -410,9 +416,25 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     return I2S_OK;
 }
 
-extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, const int* w, const int* h,
-                                const int* stride, const int* channels, const i2s_params* p,
-                                i2s_board* boards, i2s_result* full)
+// Pillow Geometry.c: #define FIX(v) FLOOR((v) * 65536.0 + 0.5), FLOOR(v) = v >= 0 ? (int)v : (int)floor(v)
+static int pil_fix(double v)
+{
+    v = v * 65536.0 + 0.5;
+    return v >= 0.0 ? (int)v : (int)floor(v);
+}
+
+// affine_fixed()'s constants: the translation is moved to the pixel centre before it is converted
+static void xform_fixed(const double a[6], XfDesc* x)
+{
+    x->a0 = pil_fix(a[0]); x->a1 = pil_fix(a[1]);
+    x->a3 = pil_fix(a[3]); x->a4 = pil_fix(a[4]);
+    x->a2 = pil_fix(a[2] + a[0] * 0.5 + a[1] * 0.5);
+    x->a5 = pil_fix(a[5] + a[3] * 0.5 + a[4] * 0.5);
+}
+
+extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* img, const int* w, const int* h,
+                                   const int* stride, const int* channels, const i2s_xform* xf, const i2s_params* p,
+                                   i2s_board* boards, i2s_result* full)
 {
     if (!ctx || B < 0 || (B > 0 && (!img || !w || !h || !stride || !channels || !boards))) return I2S_E_INVALID;
     int rc = check_params(p);
@@ -420,7 +442,13 @@ extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, 
     for (int i = 0; i < B; i++) {
         if (!img[i] || w[i] < 1 || h[i] < 1 || (channels[i] != 1 && channels[i] != 3) || stride[i] < w[i] * channels[i])
             return I2S_E_INVALID;
-        if (w[i] > ctx->max_w || h[i] > ctx->max_h) return I2S_E_TOO_LARGE;
+        if (xf) {
+            const int32_t* c = xf[i].crop;
+            if (c[2] <= c[0] || c[3] <= c[1]) return I2S_E_INVALID;
+            if (w[i] >= 32768 || h[i] >= 32768) return I2S_E_UNSUPPORTED;      // Pillow leaves its fixed-point path there
+            for (int k = 0; k < 6; k++) if (!(fabs(xf[i].affine[k]) < 32768.0)) return I2S_E_UNSUPPORTED;
+            if ((long long)c[2] - c[0] > ctx->max_w || (long long)c[3] - c[1] > ctx->max_h) return I2S_E_TOO_LARGE;
+        } else if (w[i] > ctx->max_w || h[i] > ctx->max_h) return I2S_E_TOO_LARGE;
     }
     I2S_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < 5; i++) ctx->timing[i] = 0;
@@ -428,28 +456,73 @@ extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, 
         const int nb = B - first < ctx->max_batch ? B - first : ctx->max_batch;
         int wmax = 0, hmax = 0;
         bool c1 = false, c3 = false;
+        if (xf && !p->inputs_on_device) {
+            // raw (untransformed) host sources of this pass go to their own staging buffer, grown on demand
+            size_t need = 0;
+            for (int i = 0; i < nb; i++) need += ((size_t)w[first + i] * channels[first + i] * h[first + i] + 255) & ~(size_t)255;
+            if (need > ctx->raw_bytes) {
+                I2S_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->d_raw) I2S_HIP(hipFree(ctx->d_raw));
+                ctx->d_raw = nullptr; ctx->raw_bytes = 0;
+                I2S_HIP(hipMalloc(&ctx->d_raw, need));
+                ctx->raw_bytes = need;
+            }
+        }
+        size_t raw_off = 0;
         for (int i = 0; i < nb; i++) {
             const int k = first + i;
             ImgDesc& d = ctx->h_desc[i];
-            d.w = w[k]; d.h = h[k]; d.cn = channels[k]; d.pad = 0;
-            d.line_thr = p->line_threshold > 0 ? p->line_threshold : i2s_choose_threshold(w[k], h[k]);
+            d.cn = channels[k]; d.pad = 0;
             const bool enhance = p->contrast >= 0 || p->brightness >= 0;
-            if (p->inputs_on_device && !enhance) { d.src = img[k]; d.sstride = stride[k]; }
-            else {
-                // staged copy (host inputs; device inputs that the contrast / brightness step will modify)
-                uint8_t* dst = ctx->d_src + (size_t)i * ctx->src_slot;
+            uint8_t* slot = ctx->d_src + (size_t)i * ctx->src_slot;
+            if (xf) {
+                // crop_and_rotate_image (img2sgf.py:110-114) on the device: the staged source is the cropped region
+                XfDesc& x = ctx->h_xf[i];
                 const size_t rowb = (size_t)w[k] * channels[k];
-                I2S_HIP(hipMemcpy2DAsync(dst, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k],
-                                         p->inputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-                d.src = dst; d.sstride = (int)rowb;
+                if (p->inputs_on_device) { x.src = img[k]; x.sstride = stride[k]; }
+                else {
+                    uint8_t* raw = ctx->d_raw + raw_off;
+                    I2S_HIP(hipMemcpy2DAsync(raw, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k], hipMemcpyHostToDevice, ctx->stream));
+                    x.src = raw; x.sstride = (int)rowb;
+                    raw_off += (rowb * h[k] + 255) & ~(size_t)255;
+                }
+                x.sw = w[k]; x.sh = h[k];
+                xform_fixed(xf[k].affine, &x);
+                x.cl = xf[k].crop[0]; x.ct = xf[k].crop[1]; x.pad = 0;
+                d.w = xf[k].crop[2] - xf[k].crop[0]; d.h = xf[k].crop[3] - xf[k].crop[1];
+                d.src = slot; d.sstride = d.w * d.cn;
+            } else {
+                d.w = w[k]; d.h = h[k];
+                if (p->inputs_on_device && !enhance) { d.src = img[k]; d.sstride = stride[k]; }
+                else {
+                    // staged copy (host inputs; device inputs that the contrast / brightness step will modify)
+                    const size_t rowb = (size_t)w[k] * channels[k];
+                    I2S_HIP(hipMemcpy2DAsync(slot, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k],
+                                             p->inputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+                    d.src = slot; d.sstride = (int)rowb;
+                }
             }
-            wmax = w[k] > wmax ? w[k] : wmax; hmax = h[k] > hmax ? h[k] : hmax;
+            d.line_thr = p->line_threshold > 0 ? p->line_threshold : i2s_choose_threshold(d.w, d.h);
+            wmax = d.w > wmax ? d.w : wmax; hmax = d.h > hmax ? d.h : hmax;
             c1 |= channels[k] == 1; c3 |= channels[k] == 3;
+        }
+        if (xf) {
+            I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, ctx->stream));
+            I2S_HIP(hipMemcpyAsync(ctx->d_xf, ctx->h_xf, nb * sizeof(XfDesc), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_rotate_crop, dim3(cdiv(wmax, 64), cdiv(hmax, 4), nb), dim3(64, 4), 0, ctx->stream, ctx->d_desc, ctx->d_xf);
         }
         rc = run_pass(ctx, nb, wmax, hmax, c1, c3, p, boards + first, full ? full + first : nullptr);
         if (rc) return rc;
+        if (xf) ctx->last_staged = 1;
     }
     return I2S_OK;
+}
+
+extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, const int* w, const int* h,
+                                const int* stride, const int* channels, const i2s_params* p,
+                                i2s_board* boards, i2s_result* full)
+{
+    return i2s_detect_batch_xf(ctx, B, img, w, h, stride, channels, nullptr, p, boards, full);
 }
 
 extern "C" int i2s_classify_batch(i2s_ctx* ctx, int first, int n, const i2s_params* p, i2s_board* boards, i2s_result* full)

@@ -1,3 +1,13 @@
+// Pre-processing of the source image on the device, bit-exact with the reference's Pillow calls.
+//
+// Rotate + crop (crop_and_rotate_image, img2sgf.py:110-114): Image.rotate(angle, NEAREST, fillcolor="white", center=c)
+// followed by Image.crop(box).  Pillow's nearest-neighbour affine transform (Geometry.c, affine_fixed) walks the output in
+// 16.16 fixed point: with the inverse matrix (a0 a1 a2; a3 a4 a5) in fixed point, a2 / a5 taken at the pixel centre,
+//   xin = (a2 + y * a1 + x * a0) >> 16,  yin = (a5 + y * a4 + x * a3) >> 16;  inside the source -> copy, else the fill colour.
+// crop() then takes box (l, t, r, b) of that image; parts of the box outside it read 0.  The host computes the matrix
+// exactly as Image.rotate() does (img2sgf_amd/preprocess.py) and the fixed-point constants exactly as Geometry.c does
+// (i2s_api.hip: xform_fixed); the kernel writes the cropped region into the context's staging buffer.
+//
 // Contrast / brightness enhancement of the source image on the device, bit-exact with the reference's
 // Pillow calls (img2sgf.py:141-149):
 //   ImageEnhance.Contrast(img).enhance(fc):   degenerate = grey level int(mean(L) + 0.5), L = (R*19595 + G*38470 + B*7471 + 0x8000) >> 16
@@ -9,6 +19,37 @@
 #include "i2s_types.h"
 
 namespace i2s {
+
+struct XfDesc {
+    const uint8_t* src;     // source image (host upload in the raw staging buffer, or caller's device pointer)
+    int sstride, sw, sh;    // source row stride in bytes, width, height
+    int a0, a1, a2, a3, a4, a5;   // 16.16 inverse affine matrix, a2 / a5 at the pixel centre
+    int cl, ct;             // crop origin inside the rotated image
+    int pad;
+};
+
+// grid (ceil(w_max / 64), ceil(h_max / 4), nb), block (64, 4): one output pixel per thread.  desc[b] already describes the
+// OUTPUT (cropped) image in the staging buffer.
+__global__ __launch_bounds__(256) void k_rotate_crop(const ImgDesc* __restrict__ desc, const XfDesc* __restrict__ xf)
+{
+    const int b = blockIdx.z;
+    const ImgDesc im = desc[b];
+    const XfDesc X = xf[b];
+    const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y * 4 + threadIdx.y;
+    if (ox >= im.w || oy >= im.h) return;
+    uint8_t* dst = const_cast<uint8_t*>(im.src) + (size_t)oy * im.sstride + (size_t)ox * im.cn;
+    const int x = ox + X.cl, y = oy + X.ct;              // position in the rotated image (same size as the source)
+    const uint8_t* from = nullptr;
+    int fill = 0;                                        // crop() outside the image
+    if (x >= 0 && x < X.sw && y >= 0 && y < X.sh) {
+        fill = 255;                                      // rotate()'s fillcolor "white"
+        // Pillow accumulates xx += a0 per pixel and a2 += a1 per row in int: modular arithmetic
+        const int xin = (int)((unsigned)X.a2 + (unsigned)y * (unsigned)X.a1 + (unsigned)x * (unsigned)X.a0) >> 16;
+        const int yin = (int)((unsigned)X.a5 + (unsigned)y * (unsigned)X.a4 + (unsigned)x * (unsigned)X.a3) >> 16;
+        if (xin >= 0 && xin < X.sw && yin >= 0 && yin < X.sh) from = X.src + (size_t)yin * X.sstride + (size_t)xin * im.cn;
+    }
+    for (int c = 0; c < im.cn; c++) dst[c] = from ? from[c] : (uint8_t)fill;
+}
 
 // grid (ceil(h_max / 8), nb), block 256: sum of the luma of 8 rows per workgroup -> lsum[b] (exact integer).
 __global__ __launch_bounds__(256) void k_luma_sum(const ImgDesc* __restrict__ desc, unsigned long long* __restrict__ lsum)

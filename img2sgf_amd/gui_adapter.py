@@ -8,12 +8,13 @@
 (img2sgf.py:117-204, called from 639, 723, 1077, 1134, 1140, 1178, 1181, 1191) and `identify_board` (497-543, called
 from apply_black_thresh 765) -- with versions that run the detection through the C ABI and then assign exactly the
 module globals the rest of the reference reads (draw_images 862-897, draw_board 900-952, draw_histogram 207-227,
-cluster plotting 308-327, edit_board 955-1002, to_SGF 781-810).  Everything else (Tk widgets, Pillow pre-processing,
+cluster plotting 308-327, edit_board 955-1002, to_SGF 781-810).  The Pillow pre-processing inside process_image (rotate /
+crop 110-114, contrast / brightness 141-149) runs on the device too, bit-exact with Pillow; everything else (Tk widgets,
 logging, the board editor) keeps running the reference's own code.
 """
 import numpy as np
 
-from . import pipeline
+from . import pipeline, preprocess
 
 
 def install(m, detector=None, lib=None):
@@ -48,20 +49,22 @@ def install(m, detector=None, lib=None):
             return
         m.found_grid = m.valid_grid = m.board_ready = False
         m.log("\nProcessing image")
-        m.crop_and_rotate_image()                                                # :136 (Pillow, host)
         if m.rotate_angle.get() != 0:
             m.log("Rotated by " + str(m.rotate_angle.get()) + " degrees")
-        from PIL import Image, ImageEnhance
         m.log("Contrast = " + str(m.contrast.get()))
-        region = ImageEnhance.Contrast(m.region_PIL).enhance(102 / (101 - m.contrast.get()) - 1)       # :142-144
         m.log("Brightness = " + str(m.brightness.get()))
-        region = ImageEnhance.Brightness(region).enhance(450 / (200 - m.brightness.get()) - 2)         # :147-149
-        m.region_PIL = region
-        m.input_image_np = np.array(region)                                                           # :150
-        m.log("Converting to greyscale / Canny / detecting circles / finding grid on the GPU")
-        h, w = m.input_image_np.shape[:2]
+        from PIL import Image
+        raw = np.array(m.input_image_PIL)                                                              # decoded source (:651)
+        sel = getattr(m, "selection_global", None)
+        xf = preprocess.xform(m.input_image_PIL.size, m.rotate_angle.get(), sel)                       # :110-114 on the device
+        m.log("Rotating / cropping / enhancing / converting to greyscale / Canny / detecting circles / finding grid on the GPU")
+        h, w = xf[1][3] - xf[1][1], xf[1][2] - xf[1][0]
         d = _detector(w, h)
-        det = d.detect_batch([m.input_image_np], _params(), full=True)[0]
+        p = _params()
+        p.contrast, p.brightness = int(m.contrast.get()), int(m.brightness.get())                      # :141-149 on the device
+        det = d.detect_batch([raw], p, full=True, xforms=[xf])[0]
+        m.input_image_np = d.fetch_source(0, 1 if raw.ndim == 2 else 3)                                # :150
+        m.region_PIL = Image.fromarray(m.input_image_np)
         m.grey_image_np = d.fetch_plane(0, "grey")                                                     # :153
         m.edge_detected_image_np = d.fetch_plane(0, "edges")                                           # :162
         m.edge_detected_image_PIL = Image.fromarray(m.edge_detected_image_np)                          # :166

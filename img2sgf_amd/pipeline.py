@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import I2sBoard, I2sError, I2sParams, I2sResult, PLANE_NAMES, STATUS_TEXT
+from ._lib import I2sBoard, I2sError, I2sParams, I2sResult, I2sXform, PLANE_NAMES, STATUS_TEXT
 
 BOARD_SIZE = 19                       # img2sgf.py:43
 EMPTY, BLACK, WHITE, STONE = range(4)  # BoardStates, img2sgf.py:82-83
@@ -150,21 +150,34 @@ class Detector:
                                        self.lib.dll.i2s_last_error(self._ctx).decode()))
 
     # -- raw entry: pointers may be host (numpy) or device addresses
-    def detect_ptrs(self, ptrs, ws, hs, strides, chans, params: Params, on_device, full=False):
+    def detect_ptrs(self, ptrs, ws, hs, strides, chans, params: Params, on_device, full=False, xforms=None):
+        """xforms: None, or one (affine[6], crop[4]) per image (preprocess.xform): rotate + crop on the device first."""
         B = len(ptrs)
         arr_p = (C.c_void_p * B)(*[int(p) for p in ptrs])
         mk = lambda v: (C.c_int * B)(*[int(x) for x in v])
         boards = (I2sBoard * B)()
         res = (I2sResult * B)() if full else None
         p = params.to_c(on_device)
-        rc = self.lib.dll.i2s_detect_batch(self._ctx, B, arr_p, mk(ws), mk(hs), mk(strides), mk(chans), C.byref(p),
-                                           boards, res)
+        shapes = list(zip(hs, ws))
+        if xforms is None:
+            rc = self.lib.dll.i2s_detect_batch(self._ctx, B, arr_p, mk(ws), mk(hs), mk(strides), mk(chans), C.byref(p),
+                                               boards, res)
+        else:
+            xf = (I2sXform * B)()
+            for i, (aff, crop) in enumerate(xforms):
+                xf[i].affine[:] = [float(v) for v in aff]
+                xf[i].crop[:] = [int(v) for v in crop]
+            shapes = [(x.crop[3] - x.crop[1], x.crop[2] - x.crop[0]) for x in xf]          # the cropped regions
+            rc = self.lib.dll.i2s_detect_batch_xf(self._ctx, B, arr_p, mk(ws), mk(hs), mk(strides), mk(chans), xf,
+                                                  C.byref(p), boards, res)
         self._check(rc)
-        self._last_shapes = list(zip(hs, ws))[-((B - 1) % self.max_batch + 1):]
+        self._last_shapes = shapes[-((B - 1) % self.max_batch + 1):]
         return boards, res
 
-    def detect_batch(self, images: Sequence[np.ndarray], params: Optional[Params] = None, full=True):
-        """images: HxW (grey) or HxWx3 uint8 arrays = the reference's `input_image_np` (img2sgf.py:150).
+    def detect_batch(self, images: Sequence[np.ndarray], params: Optional[Params] = None, full=True, xforms=None):
+        """images: HxW (grey) or HxWx3 uint8 arrays = the reference's `input_image_np` (img2sgf.py:150) -- or, with
+        `xforms` (one preprocess.xform(...) per image), the decoded source images, which are then rotated and cropped on the
+        device first (crop_and_rotate_image, img2sgf.py:110-114).
         Returns a list of Detection (full=True) or the raw I2sBoard array (full=False)."""
         params = params or Params()
         imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
@@ -173,7 +186,7 @@ class Detector:
                 raise ValueError("images must be HxW or HxWx3 uint8")
         boards, res = self.detect_ptrs([im.ctypes.data for im in imgs], [im.shape[1] for im in imgs],
                                        [im.shape[0] for im in imgs], [im.strides[0] for im in imgs],
-                                       [1 if im.ndim == 2 else 3 for im in imgs], params, False, full)
+                                       [1 if im.ndim == 2 else 3 for im in imgs], params, False, full, xforms)
         if not full:
             return boards
         return [_detection_from_result(r) for r in res]

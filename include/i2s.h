@@ -16,7 +16,10 @@
  *   i2s_grid_from_lines   find_grid() 546-576 with injected circles and Hough-line rho lists
  *                         (what find_grid sees after find_lines 230-255 returned).
  *   i2s_choose_threshold  choose_threshold() 606-613.
- *   i2s_fetch_source      input_image_np 150 after the on-device contrast / brightness step (141-149), if enabled.
+ *   i2s_detect_batch_xf   the same, preceded on the device by crop_and_rotate_image() 110-114
+ *                         (PIL Image.rotate(NEAREST, fillcolor white, center) + Image.crop).
+ *   i2s_fetch_source      input_image_np 150 after the on-device rotate / crop (110-114) and contrast / brightness
+ *                         (141-149) steps, if enabled.
  *   i2s_fetch_plane       the numpy images the GUI draws: grey_image_np 153,
  *                         edge_detected_image_np 162, the blur bank 171-175,
  *                         circles_removed_image_np 169-198.
@@ -170,6 +173,24 @@ void i2s_destroy(i2s_ctx* ctx);
 int  i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img,
                       const int* w, const int* h, const int* stride, const int* channels,
                       const i2s_params* p, i2s_board* boards, i2s_result* full);
+
+/* Pre-transform of one source image, applied on the device before everything else: crop_and_rotate_image() 110-114, i.e.
+ * Pillow's Image.rotate(angle, NEAREST, fillcolor="white", center=c) followed by Image.crop(box).
+ *   affine[6]: the inverse (output -> input) matrix Image.rotate() hands to Image.transform(AFFINE)
+ *              (img2sgf_amd.preprocess.rotate_matrix computes it exactly as Pillow's Python code does);
+ *   crop[4]:   (left, upper, right, lower) in the rotated image, which has the size of the source; right > left,
+ *              lower > upper; the part of the box outside the image reads 0 as with Image.crop().
+ * The detection then runs on the (right-left) x (lower-upper) region, which must fit the context's max_w x max_h. */
+typedef struct i2s_xform {
+    double  affine[6];
+    int32_t crop[4];
+} i2s_xform;
+
+/* i2s_detect_batch with a per-image pre-transform xf[B] (NULL = none, identical to i2s_detect_batch).  w/h/stride describe
+ * the SOURCE images; the contrast / brightness step of p (141-149), if enabled, follows the transform as in the reference. */
+int  i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* img,
+                         const int* w, const int* h, const int* stride, const int* channels,
+                         const i2s_xform* xf, const i2s_params* p, i2s_board* boards, i2s_result* full);
 
 /* Re-run the stone classifier on the images of the LAST pass of the last detect call
  * (first..first+n) with p->black_threshold / p->align_*; circles, lines and grid are reused. */

@@ -140,3 +140,31 @@ def test_device_contrast_brightness_matches_pillow(lib):
         np.testing.assert_array_equal(det.fetch_source(0), want)
         parity.compare_detection(d, opipe.process_image(want))
         det.close()
+
+
+def test_device_rotate_crop_matches_pillow(lib):
+    """crop_and_rotate_image (img2sgf.py:110-114) on the device against Pillow itself: the staged source must equal
+    Image.rotate(NEAREST, fillcolor white, center).crop(box) bit for bit, for L and RGB images, boxes reaching outside the
+    image included; the detection must equal the oracle's on the Pillow-transformed image."""
+    from PIL import Image
+    from img2sgf_amd import preprocess
+    rng = np.random.default_rng(21)
+    base = synth.synth_diagram(5, geom=synth.GEOM_SMALL)[0]
+    h, w = base.shape
+    rgb = np.ascontiguousarray(np.stack([base, base[::-1], rng.integers(0, 256, base.shape, dtype=np.uint8)], axis=-1))
+    cases = [(base, 0.0, None), (base, 3.5, (10, 12, w - 20, h - 8)), (rgb, -17.25, (5, 0, w - 1, h - 30)),
+             (base, 90.0, (0, 0, w, h)), (rgb, 180.0, None), (base, 45.0, (-15, -10, w + 12, h + 9)),
+             (rgb, 0.0, (30, 40, 150, 160)), (base, 271.3, (20, 20, 200, 180))]
+    det = Detector(0, 3, w + 40, h + 40, lib=lib)
+    imgs = [c[0] for c in cases]
+    xfs = [preprocess.xform((w, h), ang, sel) for (_, ang, sel) in cases]
+    dets = det.detect_batch(imgs, Params(), xforms=xfs)
+    n_last = (len(cases) - 1) % 3 + 1
+    for k, ((img, ang, sel), d) in enumerate(zip(cases, dets)):
+        s = sel if sel is not None else (0, 0, w, h)
+        ref = np.array(Image.fromarray(img).rotate(angle=-ang, fillcolor="white", center=preprocess.rectangle_centre(s)).crop(s))
+        if k >= len(cases) - n_last:
+            got = det.fetch_source(k - (len(cases) - n_last), 1 if img.ndim == 2 else 3)
+            assert got.shape == ref.shape and (got == ref).all(), (k, ang, sel)
+        parity.compare_detection(d, opipe.process_image(ref))
+    det.close()

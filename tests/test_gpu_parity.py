@@ -226,3 +226,56 @@ def test_device_contrast_brightness_all_fixtures():
             if (c, b) == (70, 50):
                 assert board_to_sgf(boards[k]) == opipe.process_image(want, keep_planes=False)["sgf"], n
     det.close()
+
+
+def test_device_rotate_crop_all_fixtures():
+    """SURVEY 8f-1, the rest of crop_and_rotate_image (img2sgf.py:110-114): raw decoded RGB in; Pillow's rotate (NEAREST, white
+    fill, the reference's centre) + crop + contrast + brightness all on the device.  The staged source must equal Pillow's
+    result bit for bit (Pillow is installed: this row is pinned by the real dependency), the SGF the oracle's."""
+    from img2sgf_amd import preprocess
+    pils = [preprocess.load_image(os.path.join(GOLDEN, "test_images", n)) for n in IMAGES]
+    raws = [np.array(p) for p in pils]
+    rng = np.random.default_rng(3)
+    det = Detector(0, len(raws), max(i.shape[1] for i in raws) + 16, max(i.shape[0] for i in raws) + 16)
+    for round_ in range(3):
+        angles = [0.0, 2.0, -1.5][round_] + rng.uniform(-0.5, 0.5, len(raws)) * (round_ > 0)
+        sels = []
+        for im in raws:
+            h, w = im.shape[:2]
+            if round_ == 0:
+                sels.append(None)
+            elif round_ == 1:
+                sels.append((int(w * 0.03), int(h * 0.02), w - int(w * 0.02), h - int(h * 0.04)))
+            else:
+                sels.append((-5, -3, w + 7, h + 2))          # reaches outside: Image.crop pads with 0
+        xfs = [preprocess.xform((im.shape[1], im.shape[0]), float(a), s) for im, a, s in zip(raws, angles, sels)]
+        boards = det.detect_batch(raws, Params(contrast=70, brightness=50), full=False, xforms=xfs)
+        for k, n in enumerate(IMAGES):
+            want = preprocess.enhance(pils[k], 70, 50, rotate_angle=float(angles[k]), selection=sels[k])
+            np.testing.assert_array_equal(det.fetch_source(k), want, err_msg="%s round %d" % (n, round_))
+            ref = opipe.process_image(want, keep_planes=False)
+            assert bool(boards[k].status == 0) == bool(ref.get("board_ready")), (n, round_)
+            if ref.get("board_ready"):
+                assert board_to_sgf(boards[k]) == ref["sgf"], (n, round_)
+    det.close()
+
+
+def test_rotate_crop_device_resident_and_errors():
+    import torch
+    from PIL import Image
+    from img2sgf_amd import preprocess
+    img = synth.synth_diagram(9)[0]
+    dev = torch.from_numpy(img[None]).cuda()
+    det = Detector(0, 1, 1024, 1024)
+    xf = preprocess.xform((1024, 1024), 1.0, (12, 8, 1010, 1000))
+    boards, _ = det.detect_ptrs([dev.data_ptr()], [1024], [1024], [1024], [1], Params(), True, False, xforms=[xf])
+    ref = np.array(Image.fromarray(img).rotate(angle=-1.0, fillcolor="white", center=preprocess.rectangle_centre((12, 8, 1010, 1000)))
+                   .crop((12, 8, 1010, 1000)))
+    np.testing.assert_array_equal(det.fetch_source(0, 1), ref)
+    assert (dev.cpu().numpy()[0] == img).all()                   # the caller's device buffer is never written
+    assert board_to_sgf(boards[0]) == opipe.process_image(ref, keep_planes=False)["sgf"]
+    with pytest.raises(Exception):                               # region larger than the context
+        det.detect_batch([img], Params(), xforms=[preprocess.xform((1024, 1024), 0.0, (-10, 0, 1024, 1024))])
+    with pytest.raises(Exception):                               # empty box
+        det.detect_batch([img], Params(), xforms=[(preprocess.rotate_matrix(0, (0, 0)), (5, 5, 5, 9))])
+    det.close()

@@ -68,3 +68,25 @@ def test_reference_app_on_gpu_path(name):
         m.identify_board()
         ref2 = opipe.process_image(opipe.load_and_enhance(path), black_thr=250)
         assert m.to_SGF(m.full_board) == ref2["sgf"]
+
+
+def test_reference_app_rotated_selection_on_gpu_path():
+    """The rotate slider and a region selection: crop_and_rotate_image runs on the device inside the adapter and must leave
+    the reference's globals exactly as its own Pillow code would."""
+    from img2sgf_amd import gui_adapter, preprocess
+    m = load_reference()
+    gui_adapter.install(m, lib=emu_util.emu_library())
+    path = os.path.join(GOLDEN, "test_images", "ex9.jpg")
+    m.open_file(path)
+    w, h = m.input_image_PIL.size
+    m.selection_global = (4, 3, w - 6, h - 5)
+    m.rotate_angle.set(1.5)
+    m.process_image()
+    want = preprocess.enhance(preprocess.load_image(path), 70, 50, rotate_angle=1.5, selection=m.selection_global)
+    np.testing.assert_array_equal(m.input_image_np, want)
+    np.testing.assert_array_equal(np.array(m.region_PIL), want)
+    ref = opipe.process_image(want, threshold=m.threshold.get())
+    assert bool(m.board_ready) == ref["board_ready"]
+    np.testing.assert_array_equal(m.edge_detected_image_np, ref["edges"])
+    if ref["board_ready"]:
+        assert m.to_SGF(m.full_board) == ref["sgf"]
