@@ -19,6 +19,7 @@ constexpr int VASTR = 129;       // dword row stride of the LDS tile (odd: verti
 constexpr int VTHREADS = 512;
 constexpr int EB = 32;           // edge bins: EB x EB pixel cells
 constexpr int EB_CAP = EB * EB;  // worst case: every pixel of a bin is an edge
+constexpr int VRING = 192;            // per-wave item ring of k_vote_centres: < 64 waiting + <= 128 new per round
 constexpr int EBB_X = 4, EBB_Y = 2;   // bins per k_edge_bins workgroup (128 x 64 pixels)
 
 // Sobel 3x3 with BORDER_REPLICATE at one pixel of a single-channel plane.
@@ -118,20 +119,22 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     }
 }
 
-// Votes of up to 32 edge records held in a per-wave LDS ring.  Lane l handles record l & 31 in direction l >> 5 and steps
-// through r = min_r .. max_r: cell = ((x * 1024 +- r * sx) >> 10, (y * 1024 +- r * sy) >> 10), relative to the first valid
-// cell of the tile.  Cells outside [0, vx_n) x [0, vy_n) (outside the image or the tile) are skipped, which equals OpenCV's
-// "break at the first cell outside the image" because a ray leaves the convex image only once.
-__device__ __forceinline__ void vote_walk32(const uint2* __restrict__ ring, int count, int lane, int vx_lo, int vy_lo,
+// Votes of up to 64 (edge record, direction) items held in a per-wave LDS ring (item = index into bin_ent | direction << 31).
+// Lane l walks item l through r = min_r .. max_r: cell = ((x * 1024 + r * sx) >> 10, (y * 1024 + r * sy) >> 10), relative to
+// the first valid cell of the tile, with (sx, sy) negated for the second direction.  Cells outside [0, vx_n) x [0, vy_n)
+// (outside the image or the tile) are skipped, which equals OpenCV's "break at the first cell outside the image" because a
+// ray leaves the convex image only once.
+__device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, int count, int lane,
+                                            const uint2* __restrict__ bin_ent, int vx_lo, int vy_lo,
                                             unsigned vx_n, unsigned vy_n, int offx, int offy, int min_r, int nsteps,
                                             unsigned* __restrict__ s_acc)
 {
-    const int ri = lane & 31;
     int sx = 0, sy = 0, x = -1024, y = -1024;          // idle lanes sit at cell (-1, -1): never in range
-    if (ri < count) {
-        const uint2 e = ring[ri];
+    if (lane < count) {
+        const unsigned item = ring[lane];
+        const uint2 e = bin_ent[item & 0x7fffffffu];   // read a moment ago by the culling pass: an L1 / L2 hit
         sx = (int)(short)(e.y & 0xffffu); sy = (int)(short)(e.y >> 16);
-        if (lane >= 32) { sx = -sx; sy = -sy; }
+        if (item >> 31) { sx = -sx; sy = -sy; }
         x = (((int)(e.x & 0xffffu) - vx_lo) << 10) + min_r * sx;
         y = (((int)(e.x >> 16) - vy_lo) << 10) + min_r * sy;
     }
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
 {
     __shared__ unsigned s_acc[(VL / 2) * VASTR];
     __shared__ int s_ticket;
-    __shared__ uint2 s_ring[VTHREADS / 64][96];
+    __shared__ unsigned s_ring[VTHREADS / 64][VRING];
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z / NVAR, v = tl.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
@@ -213,10 +216,10 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
         ent_cur = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, q) * EB_CAP;
         if (lane < n_cur) mine = ent_cur[lane];
     }
-    // Survivors of the reach test are compacted into a per-wave LDS ring; whenever 32 are waiting they are walked
-    // together: lane = (record, direction), the radius steps run as a loop with two adds per step.  This costs ~12 vector
-    // instructions per 64 votes instead of ~19 per 60 for the one-record-per-iteration walk it replaces.
-    uint2* ring = s_ring[wave];
+    // The reach test is made per DIRECTION (a ray that points away from the tile would only occupy a lane for 30 steps):
+    // surviving (record, direction) items are compacted into a per-wave LDS ring; whenever 64 are waiting they are walked
+    // together, one item per lane, the radius steps as a loop with two adds per step.
+    unsigned* ring = s_ring[wave];
     int fill = 0;
     while (q < nbin) {
         int qn = 0;
@@ -230,34 +233,48 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
             ent_next = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, qn) * EB_CAP;
             if (lane < n_next) mine_next = ent_next[lane];
         }
+        const unsigned ent_base = (unsigned)(ent_cur - bin_ent);
         for (int k0 = 0; k0 < n_cur; k0 += 64) {
             if (k0 > 0) { mine = make_uint2(0u, 0u); if (k0 + lane < n_cur) mine = ent_cur[k0 + lane]; }
-            bool reach = false;
+            bool reach_p = false, reach_n = false;
             if (k0 + lane < n_cur) {
                 const int sxv = (int)(short)(mine.y & 0xffffu), syv = (int)(short)(mine.y >> 16);
                 const int exr = (int)(mine.x & 0xffffu) - vx_lo, eyr = (int)(mine.x >> 16) - vy_lo;
-                // the 2 * nsteps vote cells lie within +-(max_r * |s| >> 10) + 1 of the pixel on each axis
-                const int ddx = ((max_r * iabs_(sxv)) >> 10) + 1, ddy = ((max_r * iabs_(syv)) >> 10) + 1;
-                reach = exr + ddx >= 0 && exr - ddx < (int)vx_n && eyr + ddy >= 0 && eyr - ddy < (int)vy_n;
+                // the cells of direction +1 lie between the pixel and pixel + ((max_r * s) >> 10) on each axis (+-1 for the
+                // floor), those of direction -1 between the pixel and pixel + ((-max_r * s) >> 10)
+                const int dxp = (max_r * sxv) >> 10, dyp = (max_r * syv) >> 10;
+                const int dxn = (-max_r * sxv) >> 10, dyn = (-max_r * syv) >> 10;
+                reach_p = exr + imax(dxp, 0) + 1 >= 0 && exr + imin(dxp, 0) - 1 < (int)vx_n &&
+                          eyr + imax(dyp, 0) + 1 >= 0 && eyr + imin(dyp, 0) - 1 < (int)vy_n;
+                reach_n = exr + imax(dxn, 0) + 1 >= 0 && exr + imin(dxn, 0) - 1 < (int)vx_n &&
+                          eyr + imax(dyn, 0) + 1 >= 0 && eyr + imin(dyn, 0) - 1 < (int)vy_n;
             }
-            const unsigned long long m = __ballot(reach);
-            if (reach) ring[fill + __popcll(m & ((1ull << lane) - 1ull))] = mine;
-            fill += __popcll(m);
+            const unsigned item = ent_base + (unsigned)(k0 + lane);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long mp = __ballot(reach_p);
+            if (reach_p) ring[fill + __popcll(mp & below)] = item;
+            fill += __popcll(mp);
+            const unsigned long long mn = __ballot(reach_n);
+            if (reach_n) ring[fill + __popcll(mn & below)] = item | 0x80000000u;
+            fill += __popcll(mn);
             __builtin_amdgcn_wave_barrier();
-            while (fill >= 32) {
-                vote_walk32(ring, 32, lane, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
-                // move the remainder to the front
-                uint2 tmp = make_uint2(0u, 0u);
-                if (lane < fill - 32) tmp = ring[32 + lane];
+            while (fill >= 64) {
+                vote_walk64(ring, 64, lane, bin_ent, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+                // move the remainder (< 128 items) to the front
+                const int rem = fill - 64;
+                unsigned t0 = 0, t1 = 0;
+                if (lane < rem) t0 = ring[64 + lane];
+                if (64 + lane < rem) t1 = ring[128 + lane];
                 __builtin_amdgcn_wave_barrier();
-                if (lane < fill - 32) ring[lane] = tmp;
-                fill -= 32;
+                if (lane < rem) ring[lane] = t0;
+                if (64 + lane < rem) ring[64 + lane] = t1;
+                fill = rem;
                 __builtin_amdgcn_wave_barrier();
             }
         }
         q = qn; n_cur = n_next; ent_cur = ent_next; mine = mine_next;
     }
-    if (fill > 0) vote_walk32(ring, fill, lane, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+    if (fill > 0) vote_walk64(ring, fill, lane, bin_ent, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
     __syncthreads();
     // centre candidates: cells (x,y), 1 <= x <= w-1, 1 <= y <= h-1 (OpenCV scans padded rows 1..H, cols 1..W
     // of an accumulator whose votes sit at unpadded indices; cells x == W or y == H hold no votes).
