@@ -421,25 +421,44 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
         for (int q = 0; q < PERL; q++) bins[lane * PERL + q] = loc[q] + excl;
         __builtin_amdgcn_wave_barrier();
         if (live) {
+            // OpenCV scans the histogram from the top: take the highest non-empty bin u <= j, sum the 10 bins below it
+            // (lo = u - 10), compare, continue at j = lo - 1.  WHICH bins get visited depends on the occupancy masks alone, so
+            // that part runs as a scalar bit loop, one statically indexed 64-bin word after the other (a dynamically indexed
+            // mask array costs a select chain per step on the scalar unit the whole CU shares), and hands visited bin k to
+            // lane k; the window sums and radii of all visited bins are then formed in parallel (one LDS round trip, one
+            // division), and only the order-dependent comparison chain is folded sequentially, reading lane k's candidate with
+            // v_readlane.
+            int u_mine = 0, nv = 0;
+            int j = nBins - 1;
+#pragma unroll
+            for (int q = RAD_BINS_MAX / 64 - 1; q >= 0; q--) {
+                const unsigned long long wq = q == 0 ? (occ[0] & ~1ull) : occ[q];       // a visited bin has u >= 1
+                while (j > 0 && j >= q * 64) {
+                    const int top = imin(j - q * 64, 63);
+                    const unsigned long long m = top < 63 ? (wq & ((2ull << top) - 1ull)) : wq;
+                    if (!m) break;                                   // nothing at or below j in this word: go on in the next one
+                    const int u = q * 64 + 63 - __clzll((long long)m);
+                    if (lane == nv) u_mine = u;
+                    nv++;
+                    j = imax(u - nBinsPerDr, -1) - 1;               // lo - 1: the outer loop's own j--
+                }
+            }
+            int c_cnt = 0, c_s = 0;
+            float c_r = 0.f;
+            if (lane < nv) {
+                const int lo = imax(u_mine - nBinsPerDr, -1);       // j after OpenCV's inner summing loop
+                c_cnt = bins[u_mine] - (lo >= 0 ? bins[lo] : 0);
+                c_r = (float)(u_mine + lo) / 2.f / (float)nBinsPerDr * 1.0f + (float)min_r;
+                c_s = u_mine + lo;
+            }
             int maxCount = 0, sBest = 0;
             float rBest = 0.f;
-            int j = nBins - 1;
-            while (j > 0) {
-                // highest non-empty bin u with 1 <= u <= j
-                int u = -1;
-                for (int q = j >> 6; q >= 0; q--) {
-                    unsigned long long mq = occ[q];
-                    if (q == (j >> 6)) { const int top = j & 63; if (top < 63) mq &= (2ull << top) - 1ull; }
-                    if (mq) { u = q * 64 + 63 - __clzll((long long)mq); break; }
-                }
-                if (u < 1) break;
-                const int lo = imax(u - nBinsPerDr, -1);          // j after OpenCV's inner summing loop
-                const int curCount = bins[u] - (lo >= 0 ? bins[lo] : 0);
-                const float rCur = (float)(u + lo) / 2.f / (float)nBinsPerDr * 1.0f + (float)min_r;
+            for (int k = 0; k < nv; k++) {
+                const int curCount = __builtin_amdgcn_readlane(c_cnt, k);
+                const float rCur = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_r), k));
                 if (((float)curCount * rBest >= (float)maxCount * rCur) || (rBest < 1.1920929e-07f && curCount >= maxCount)) {
-                    rBest = rCur; maxCount = curCount; sBest = u + lo;
+                    rBest = rCur; maxCount = curCount; sBest = __builtin_amdgcn_readlane(c_s, k);
                 }
-                j = lo - 1;                                        // the outer loop's own j--
             }
             if (lane == 0 && maxCount > acc_thr) {
                 const int k = atomicAdd(&est_count[bv], 1);

@@ -130,6 +130,8 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
 {
     return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (shift & 31));
 }
+static inline int __float_as_int(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
 static inline int __mul24(int a, int b) { return a * b; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }
