@@ -27,11 +27,28 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
     uint8_t* o = grey + (size_t)b * g.slot + (size_t)y * g.pitch;
     int cb, cg, cr;
     if (shift == 14) { cb = 1868; cg = 9617; cr = 4899; } else { cb = 3735; cg = 19235; cr = 9798; }
+    const int half = 1 << (shift - 1);
+    if (x0 + 3 < im.w && ((reinterpret_cast<size_t>(im.src) | (size_t)im.sstride) & 3) == 0) {
+        // whole dwords (the usual case: numpy / torch rows start 4-byte aligned)
+        unsigned out;
+        if (im.cn == 1) out = *reinterpret_cast<const unsigned*>(s + x0);
+        else {
+            const unsigned* s3 = reinterpret_cast<const unsigned*>(s + 3 * x0);
+            const unsigned d0 = s3[0], d1 = s3[1], d2 = s3[2];            // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+            const unsigned g0 = ((d0 & 0xffu) * cb + ((d0 >> 8) & 0xffu) * cg + ((d0 >> 16) & 0xffu) * cr + half) >> shift;
+            const unsigned g1 = ((d0 >> 24) * cb + (d1 & 0xffu) * cg + ((d1 >> 8) & 0xffu) * cr + half) >> shift;
+            const unsigned g2 = (((d1 >> 16) & 0xffu) * cb + (d1 >> 24) * cg + (d2 & 0xffu) * cr + half) >> shift;
+            const unsigned g3 = (((d2 >> 8) & 0xffu) * cb + ((d2 >> 16) & 0xffu) * cg + (d2 >> 24) * cr + half) >> shift;
+            out = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        }
+        *reinterpret_cast<unsigned*>(o + x0) = out;
+        return;
+    }
     for (int i = 0; i < 4; i++) {
         const int x = x0 + i;
         if (x >= im.w) break;
         if (im.cn == 1) o[x] = s[x];
-        else o[x] = (uint8_t)((s[3 * x] * cb + s[3 * x + 1] * cg + s[3 * x + 2] * cr + (1 << (shift - 1))) >> shift);
+        else o[x] = (uint8_t)((s[3 * x] * cb + s[3 * x + 1] * cg + s[3 * x + 2] * cr + half) >> shift);
     }
 }
 
