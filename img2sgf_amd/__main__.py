@@ -37,7 +37,7 @@ def main(argv=None):
     out_h = [x[1][3] - x[1][1] for x in xforms] if xforms else [i.shape[0] for i in images]
     det = pipeline.Detector(args.device, min(len(images), 16), max(out_w), max(out_h))
     params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
-                             contrast=args.contrast, brightness=args.brightness)
+                             contrast=args.contrast, brightness=args.brightness, schedule=True)
     rc = 0
     for path, d in zip(inputs, det.detect_batch(images, params, xforms=xforms)):
         name = os.path.splitext(os.path.basename(path))[0] + ".sgf"

@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "i2s_types.h"
 #include "k_canny.h"
 #include "k_erase_lines.h"
@@ -93,7 +96,7 @@ extern "C" void i2s_default_params(i2s_params* p)
     p->line_threshold = 0; p->black_threshold = 128;
     p->align_x = I2S_ALIGN_LEFT; p->align_y = I2S_ALIGN_TOP;
     p->min_grid_spacing = 10; p->big_space_ratio = 1.6; p->angle_tolerance_deg = 1.0;
-    p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 0; p->inputs_on_device = 0;
+    p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 0; p->inputs_on_device = 0; p->schedule = 0; p->pad_ = 0;
     p->contrast = -1; p->brightness = -1;
 }
 
@@ -295,10 +298,23 @@ static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// One device pass over nb images whose descriptors are already in h_desc.
-static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool has_c3, const i2s_params* p,
-                    i2s_board* boards, i2s_result* full)
+// Copy an image into a densely packed staging slot.  Contiguous sources (the usual numpy / torch case) go as ONE linear
+// copy: hipMemcpy2DAsync falls back to a row-by-row path (~8.5 us per row, measured) when the row width is not a multiple
+// of 4 bytes, which made real RGB scans with odd widths 10x slower end to end than their GPU time.
+static hipError_t stage_image(uint8_t* dst, const uint8_t* src, size_t rowb, size_t stride, size_t rows, hipMemcpyKind kind,
+                              hipStream_t st)
 {
+    if (stride == rowb) return hipMemcpyAsync(dst, src, rowb * rows, kind, st);
+    return hipMemcpy2DAsync(dst, rowb, src, stride, rowb, rows, kind, st);
+}
+
+// One device pass over nb images whose descriptors are already in h_desc.
+// Results of image i go to boards[dst[i]] / full[dst[i]].
+static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool has_c3, const i2s_params* p,
+                    i2s_board* boards, i2s_result* full, const int* dst)
+{
+    bool dense = true;
+    for (int i = 1; i < nb; i++) dense &= dst[i] == dst[0] + i;
     Geo& g = ctx->geo;
     g.nb = nb;
     hipStream_t st = ctx->stream;
@@ -392,7 +408,9 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipEventRecord(ctx->ev[4], st));
 
         I2S_HIP(hipMemcpyAsync(ctx->h_boards, ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToHost, st));
-        if (full) I2S_HIP(hipMemcpyAsync(full, ctx->d_res, nb * sizeof(i2s_result), hipMemcpyDeviceToHost, st));
+        if (full && dense) I2S_HIP(hipMemcpyAsync(full + dst[0], ctx->d_res, nb * sizeof(i2s_result), hipMemcpyDeviceToHost, st));
+        else if (full) for (int i = 0; i < nb; i++)
+            I2S_HIP(hipMemcpyAsync(full + dst[i], ctx->d_res + i, sizeof(i2s_result), hipMemcpyDeviceToHost, st));
         I2S_HIP(hipStreamSynchronize(st));
         I2S_HIP(hipGetLastError());
         if (ctx->h_flags[0] == 0 && ctx->h_flags[1] == 0) break;
@@ -403,7 +421,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         }
         ctx->hyst_passes = ctx->hyst_passes * 2 < HYST_MAX_PASSES ? ctx->hyst_passes * 2 : HYST_MAX_PASSES;
     }
-    memcpy(boards, ctx->h_boards, nb * sizeof(i2s_board));
+    for (int i = 0; i < nb; i++) boards[dst[i]] = ctx->h_boards[i];
     float ms;
     for (int i = 0; i < 4; i++) {
         I2S_HIP(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
@@ -452,6 +470,15 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
     }
     I2S_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < 5; i++) ctx->timing[i] = 0;
+    // pass formation: input order, or (ragged batches) ascending processed area so that similar sizes share a pass
+    std::vector<int> order(B);
+    for (int i = 0; i < B; i++) order[i] = i;
+    if (p->schedule && B > ctx->max_batch) {
+        auto area = [&](int i) {
+            return xf ? (long long)(xf[i].crop[2] - xf[i].crop[0]) * (xf[i].crop[3] - xf[i].crop[1]) : (long long)w[i] * h[i];
+        };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area(a) < area(b); });
+    }
     for (int first = 0; first < B; first += ctx->max_batch) {
         const int nb = B - first < ctx->max_batch ? B - first : ctx->max_batch;
         int wmax = 0, hmax = 0;
@@ -459,7 +486,10 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
         if (xf && !p->inputs_on_device) {
             // raw (untransformed) host sources of this pass go to their own staging buffer, grown on demand
             size_t need = 0;
-            for (int i = 0; i < nb; i++) need += ((size_t)w[first + i] * channels[first + i] * h[first + i] + 255) & ~(size_t)255;
+            for (int i = 0; i < nb; i++) {
+                const int k = order[first + i];
+                need += ((size_t)w[k] * channels[k] * h[k] + 255) & ~(size_t)255;
+            }
             if (need > ctx->raw_bytes) {
                 I2S_HIP(hipStreamSynchronize(ctx->stream));
                 if (ctx->d_raw) I2S_HIP(hipFree(ctx->d_raw));
@@ -470,7 +500,7 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
         }
         size_t raw_off = 0;
         for (int i = 0; i < nb; i++) {
-            const int k = first + i;
+            const int k = order[first + i];
             ImgDesc& d = ctx->h_desc[i];
             d.cn = channels[k]; d.pad = 0;
             const bool enhance = p->contrast >= 0 || p->brightness >= 0;
@@ -482,7 +512,7 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
                 if (p->inputs_on_device) { x.src = img[k]; x.sstride = stride[k]; }
                 else {
                     uint8_t* raw = ctx->d_raw + raw_off;
-                    I2S_HIP(hipMemcpy2DAsync(raw, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k], hipMemcpyHostToDevice, ctx->stream));
+                    I2S_HIP(stage_image(raw, img[k], rowb, (size_t)stride[k], (size_t)h[k], hipMemcpyHostToDevice, ctx->stream));
                     x.src = raw; x.sstride = (int)rowb;
                     raw_off += (rowb * h[k] + 255) & ~(size_t)255;
                 }
@@ -497,8 +527,8 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
                 else {
                     // staged copy (host inputs; device inputs that the contrast / brightness step will modify)
                     const size_t rowb = (size_t)w[k] * channels[k];
-                    I2S_HIP(hipMemcpy2DAsync(slot, rowb, img[k], (size_t)stride[k], rowb, (size_t)h[k],
-                                             p->inputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+                    I2S_HIP(stage_image(slot, img[k], rowb, (size_t)stride[k], (size_t)h[k],
+                                        p->inputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
                     d.src = slot; d.sstride = (int)rowb;
                 }
             }
@@ -511,7 +541,7 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
             I2S_HIP(hipMemcpyAsync(ctx->d_xf, ctx->h_xf, nb * sizeof(XfDesc), hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(k_rotate_crop, dim3(cdiv(wmax, 64), cdiv(hmax, 4), nb), dim3(64, 4), 0, ctx->stream, ctx->d_desc, ctx->d_xf);
         }
-        rc = run_pass(ctx, nb, wmax, hmax, c1, c3, p, boards + first, full ? full + first : nullptr);
+        rc = run_pass(ctx, nb, wmax, hmax, c1, c3, p, boards, full, order.data() + first);
         if (rc) return rc;
         if (xf) ctx->last_staged = 1;
     }
@@ -574,15 +604,34 @@ extern "C" int i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int
     return I2S_OK;
 }
 
+// Device -> host copy of `rows` rows of `rowb` bytes.  Dense on both sides: one linear copy.  Otherwise the whole pitched
+// block comes over in one linear copy as well and the rows are compacted on the host (hipMemcpy2D's row-by-row path for widths
+// that are not a multiple of 4 bytes costs ~8.5 us per row).
+static int fetch_rows(i2s_ctx* ctx, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_pitch, size_t rowb, size_t rows)
+{
+    if (dst_stride == rowb && src_pitch == rowb) {
+        I2S_HIP(hipMemcpyAsync(dst, src, rowb * rows, hipMemcpyDeviceToHost, ctx->stream));
+        I2S_HIP(hipStreamSynchronize(ctx->stream));
+        return I2S_OK;
+    }
+    const size_t bytes = src_pitch * (rows - 1) + rowb;
+    uint8_t* tmp = (uint8_t*)malloc(bytes);
+    if (!tmp) return I2S_E_INVALID;
+    hipError_t e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) for (size_t y = 0; y < rows; y++) memcpy(dst + y * dst_stride, tmp + y * src_pitch, rowb);
+    free(tmp);
+    I2S_HIP(e);
+    return I2S_OK;
+}
+
 extern "C" int i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* dst, size_t dst_stride)
 {
     if (!ctx || !dst || index < 0 || index >= ctx->last_nb || plane_id < 0 || plane_id >= NPLANES) return I2S_E_INVALID;
     const ImgDesc& d = ctx->h_desc[index];
     if (dst_stride < (size_t)d.w) return I2S_E_INVALID;
     const uint8_t* src = plane_ptr(ctx, plane_id) + (size_t)index * ctx->geo.slot;
-    I2S_HIP(hipMemcpy2DAsync(dst, dst_stride, src, ctx->geo.pitch, d.w, d.h, hipMemcpyDeviceToHost, ctx->stream));
-    I2S_HIP(hipStreamSynchronize(ctx->stream));
-    return I2S_OK;
+    return fetch_rows(ctx, dst, dst_stride, src, ctx->geo.pitch, (size_t)d.w, (size_t)d.h);
 }
 
 extern "C" int i2s_fetch_source(i2s_ctx* ctx, int index, uint8_t* dst, size_t dst_stride)
@@ -591,9 +640,7 @@ extern "C" int i2s_fetch_source(i2s_ctx* ctx, int index, uint8_t* dst, size_t ds
     const ImgDesc& d = ctx->h_desc[index];
     const size_t rowb = (size_t)d.w * d.cn;
     if (dst_stride < rowb) return I2S_E_INVALID;
-    I2S_HIP(hipMemcpy2DAsync(dst, dst_stride, d.src, (size_t)d.sstride, rowb, d.h, hipMemcpyDeviceToHost, ctx->stream));
-    I2S_HIP(hipStreamSynchronize(ctx->stream));
-    return I2S_OK;
+    return fetch_rows(ctx, dst, dst_stride, d.src, (size_t)d.sstride, rowb, (size_t)d.h);
 }
 
 extern "C" int i2s_last_timing(const i2s_ctx* ctx, float ms[5])

@@ -114,6 +114,10 @@ typedef struct i2s_params {
     /* Pillow pre-processing on the device (img2sgf.py:141-149): contrast / brightness slider values 0..100, the
      * reference's defaults are 70 / 50.  -1 (default) = off: img[] already is `input_image_np` (:150). */
     int32_t contrast, brightness;
+    /* Ragged batches: != 0 lets a call with more images than one device pass holds form its passes over the
+     * images sorted by area, so that a pass's tile grids (sized for its largest image) are not mostly empty; results are
+     * returned in input order.  The "last pass" the fetch / classify calls refer to is then the pass of the largest images. */
+    int32_t schedule, pad_;
 } i2s_params;
 
 /* Compact per-image record: what the SGF writer needs (to_SGF 781-810) and what ranks

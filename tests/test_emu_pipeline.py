@@ -168,3 +168,25 @@ def test_device_rotate_crop_matches_pillow(lib):
             assert got.shape == ref.shape and (got == ref).all(), (k, ang, sel)
         parity.compare_detection(d, opipe.process_image(ref))
     det.close()
+
+
+def test_scheduled_ragged_batch_returns_input_order(lib):
+    """Params.schedule: passes formed over the images sorted by area; results must come back in input order and equal the
+    unscheduled ones (with and without a device pre-transform)."""
+    import ctypes as C
+    from img2sgf_amd import preprocess
+    a = synth.synth_diagram(6, geom=synth.GEOM_SMALL)[0]
+    imgs = [a, np.ascontiguousarray(a[:120, :130]), np.pad(a, ((4, 9), (7, 3)), constant_values=255),
+            np.ascontiguousarray(a[20:220, 10:200]), np.ascontiguousarray(a[:60, :70]), a[::-1].copy(), np.ascontiguousarray(a[:, :150])]
+    det = Detector(0, 3, 330, 300, lib=lib)
+    plain = det.detect_batch(imgs, Params(), full=False)
+    sched = det.detect_batch(imgs, Params(schedule=True), full=False)
+    for k in range(len(imgs)):
+        assert bytes(plain[k]) == bytes(sched[k]), k
+    xfs = [preprocess.xform((i.shape[1], i.shape[0]), 2.0 * k, None) for k, i in enumerate(imgs)]
+    plain = det.detect_batch(imgs, Params(), full=True, xforms=xfs)
+    sched = det.detect_batch(imgs, Params(schedule=True), full=True, xforms=xfs)
+    for k in range(len(imgs)):
+        assert plain[k].sgf == sched[k].sgf and plain[k].status == sched[k].status, k
+        np.testing.assert_array_equal(plain[k].circles_all, sched[k].circles_all)
+    det.close()

@@ -279,3 +279,18 @@ def test_rotate_crop_device_resident_and_errors():
     with pytest.raises(Exception):                               # empty box
         det.detect_batch([img], Params(), xforms=[(preprocess.rotate_matrix(0, (0, 0)), (5, 5, 5, 9))])
     det.close()
+
+
+def test_scheduled_ragged_batch_all_fixtures():
+    """SURVEY 8f-4 (ragged-batch scheduler): 36 real images in shuffled order through 5-image passes formed by area; every
+    board record must equal the one the image gets on its own."""
+    raws = [opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n)) for n in IMAGES]
+    rng = np.random.default_rng(8)
+    order = rng.permutation(2 * len(raws))
+    batch = [raws[i % len(raws)] for i in order]
+    det = Detector(0, 5, max(i.shape[1] for i in raws), max(i.shape[0] for i in raws))
+    single = [bytes(det.detect_batch([r], Params(), full=False)[0]) for r in raws]
+    boards = det.detect_batch(batch, Params(schedule=True), full=False)
+    for k, i in enumerate(order):
+        assert bytes(boards[k]) == single[i % len(raws)], (k, IMAGES[i % len(raws)])
+    det.close()
