@@ -295,6 +295,31 @@ class StreamedDetector:
             pos += len(part)
         return out
 
+    def detect_batch(self, images: Sequence[np.ndarray], params: Optional[Params] = None, xforms=None):
+        """Host images (ragged sizes allowed): the passes are formed over the images sorted by area and dealt
+        to the streams round-robin, so uploads of one stream overlap with kernels of another and every stream gets small
+        and large passes alike.  Returns the (B,) I2sBoard array in input order."""
+        B, n, mb = len(images), len(self.dets), self.max_batch
+        def area(i):
+            if xforms is not None:
+                c = xforms[i][1]
+                return (c[2] - c[0]) * (c[3] - c[1])
+            return images[i].shape[0] * images[i].shape[1]
+        order = sorted(range(B), key=area)
+        passes = [order[k:k + mb] for k in range(0, B, mb)]
+        share = [[i for ps in passes[s::n] for i in ps] for s in range(n)]
+        def run(s):
+            idx = share[s]
+            xf = [xforms[i] for i in idx] if xforms is not None else None
+            return self.dets[s].detect_batch([images[i] for i in idx], params, full=False, xforms=xf)
+        futs = [(s, self.pool.submit(run, s)) for s in range(n) if share[s]]
+        out = (I2sBoard * B)()
+        for s, f in futs:
+            part = f.result()
+            for j, i in enumerate(share[s]):
+                out[i] = part[j]
+        return out
+
     def last_timing(self):
         t = [d.last_timing() for d in self.dets]
         return {k: sum(x[k] for x in t) for k in t[0]}

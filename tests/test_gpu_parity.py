@@ -294,3 +294,19 @@ def test_scheduled_ragged_batch_all_fixtures():
     for k, i in enumerate(order):
         assert bytes(boards[k]) == single[i % len(raws)], (k, IMAGES[i % len(raws)])
     det.close()
+
+
+def test_streamed_host_batch_matches_single_stream():
+    """StreamedDetector.detect_batch: ragged host images dealt to 3 streams by area-sorted passes; same records, input order."""
+    from img2sgf_amd.pipeline import StreamedDetector
+    raws = [opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n)) for n in IMAGES]
+    batch = [raws[i % len(raws)] for i in np.random.default_rng(9).permutation(2 * len(raws))]
+    mw, mh = max(i.shape[1] for i in raws), max(i.shape[0] for i in raws)
+    det = Detector(0, 8, mw, mh)
+    want = det.detect_batch(batch, Params(), full=False)
+    det.close()
+    sd = StreamedDetector(0, 3, 4, mw, mh)
+    got = sd.detect_batch(batch, Params())
+    sd.close()
+    for k in range(len(batch)):
+        assert bytes(got[k]) == bytes(want[k]), k

@@ -27,3 +27,15 @@ for name, params in (("input order", Params()), ("scheduled", Params(schedule=Tr
     print("%-12s %.1f ms for %d images (%.0f img/s, %.0f Mpx/s)" % (name, dt * 1e3, len(mixed), len(mixed) / dt,
                                                                   sum(i.shape[0] * i.shape[1] for i in mixed) / dt / 1e6))
 det.close()
+from img2sgf_amd.pipeline import StreamedDetector      # noqa: E402
+ref = None
+for n_streams in (2, 3, 4):
+    sd = StreamedDetector(0, n_streams, 16, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    sd.detect_batch(mixed[:48])
+    for rep in range(2):
+        t = time.perf_counter()
+        boards = sd.detect_batch(mixed)
+        dt = time.perf_counter() - t
+    print("%d streams    %.1f ms for %d images (%.0f img/s, %.0f Mpx/s)" % (n_streams, dt * 1e3, len(mixed), len(mixed) / dt,
+                                                                        sum(i.shape[0] * i.shape[1] for i in mixed) / dt / 1e6))
+    sd.close()
