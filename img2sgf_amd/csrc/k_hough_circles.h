@@ -3,9 +3,9 @@
 //   k_edge_bins     : edge pixels -> 8-byte records (position + fixed-point unit gradient) binned by 32x32 cell.
 //   k_vote_centres  : the 2-D accumulator never exists in HBM.  Each workgroup owns a 126x126 block of
 //                     accumulator cells (+1-cell apron) as a 33 KB LDS tile of 16-bit counters, streams the edge
-//                     bins within reach, casts the votes with LDS atomics (one wavefront per edge record, one lane
-//                     per ray step) and tests the 4-neighbour local-maximum rule in place; only centre candidates
-//                     leave the CU.
+//                     bins within reach, casts the votes with LDS atomics (64 (record, direction) rays per
+//                     wavefront, one lane each, stepping through the radii together) and tests the 4-neighbour
+//                     local-maximum rule in place; only centre candidates leave the CU.
 //   k_radius        : one wavefront per centre: 10-bins-per-pixel radius histogram of the edge bitmap in LDS.
 //   k_circles_final : per (image, variant) bitonic sort by OpenCV's total order + greedy min-dist pass.
 #pragma once
@@ -155,12 +155,13 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
 //
 // Votes of one edge pixel: cells ((x*1024 +- r*sx) >> 10, (y*1024 +- r*sy) >> 10), r = min_r..max_r, that lie inside the
 // image (OpenCV walks r upward and breaks at the first cell outside; the walk is a straight line from inside a convex
-// image, so "break" == "skip every outside cell").  The (edge, direction, r) items are independent: one wavefront
-// takes one edge record per round, lane = direction * nsteps + step.  The 2-D accumulator never exists in HBM: each
+// image, so "break" == "skip every outside cell").  The (edge, direction, r) votes are therefore independent: a wavefront
+// walks 64 (edge, direction) rays at a time, one per lane (vote_walk64).  The 2-D accumulator never exists in HBM: each
 // workgroup owns 126x126 cells (+1-cell apron) in LDS and tests the 4-neighbour local-maximum rule in place.
 // Cell counts are 16-bit halves of LDS dwords: a cell receives at most 3 votes from each of the < 3100 edge pixels
 // within max_r <= 30 of it, so a half never carries into its neighbour.  The two halves of a dword are cells 64 rows
-// apart, so the <= 31 consecutive cells of one ray never share a dword (no same-address serialisation of the atomics).
+// apart: neighbouring cells, which rays of neighbouring edge pixels hit in the same instruction, never share a dword
+// (same-address LDS atomics serialise, ~4 cycles per extra lane: profiles/r01_g_lds_atomic_microbench.txt).
 // (Measured: plain 32-bit cells halve the resident workgroups per CU and run 1.5x slower; a branch-free variant that
 // lets out-of-tile lanes add 0 to clamped cells runs 1.4x slower because of same-address conflicts.)
 __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict__ desc, Geo g,
