@@ -110,9 +110,14 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         s_cos[tid] = n < trig.n[c] ? trig.cos_[c][n] : 0.f;
         s_sin[tid] = n < trig.n[c] ? trig.sin_[c][n] : 0.f;
     }
-    int best[8];
+    // this thread's 8 pixels: 4 consecutive columns x0 + 4 * (tid & 15) .. + 3 on the two rows y0 + (tid >> 4) and + 16 (dword
+    // loads / stores of the planes; per circle one strip test, then 4 column and 2 row tests)
+    int best[2][4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) best[k] = -1;
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) best[k][q] = -1;
+    const int lx0 = 4 * (tid & 15), ly0 = tid >> 4;
     // circles whose erase box touches this tile: the per-tile list built by k_concat_circles (order irrelevant: the
     // largest index wins), or every circle of the image when that list overflowed
     const size_t tslot = (size_t)b * g.tiles + (size_t)tl.ty * g.tw + tl.tx;
@@ -139,15 +144,18 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         __syncthreads();
         const int n = s_n;
         {
-            // this thread's 8 pixels share one column (x0 + (tid & 63)) and lie on rows y0 + (tid >> 6) + 4k
-            const int px = x0 + (tid & (ET_W - 1)), py0 = y0 + (tid >> 6);
+            const int px = x0 + lx0, py = y0 + ly0;
             for (int j = 0; j < n; j++) {
-                if (px < s_box[j][0] || px > s_box[j][1]) continue;
+                const int bx0 = s_box[j][0], bx1 = s_box[j][1];
+                if (px + 3 < bx0 || px > bx1) continue;
                 const int by0 = s_box[j][2], by1 = s_box[j][3], idx = s_idx[j];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int py = py0 + 4 * k;
-                    if (py >= by0 && py <= by1) best[k] = imax(best[k], idx);
+                for (int k = 0; k < 2; k++) {
+                    const int yy = py + 16 * k;
+                    if (yy < by0 || yy > by1) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (px + q >= bx0 && px + q <= bx1) best[k][q] = imax(best[k][q], idx);
                 }
             }
         }
@@ -159,20 +167,29 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     if (tid == 0) s_n = 0;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int p = tid + k * 256;
-        const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
+    for (int k = 0; k < 2; k++) {
+        const int ly = ly0 + 16 * k;
+        const int px = x0 + lx0, py = y0 + ly;
         if (px >= w || py >= h) continue;
-        uint8_t val;
-        if (best[k] >= 0) {
-            const int mx = __float2int_rn(R->circles[best[k]][0]), my = __float2int_rn(R->circles[best[k]][1]);
-            const bool plus = (px == mx && iabs_(py - my) <= 1) || (py == my && iabs_(px - mx) <= 1);
-            val = plus ? 255 : 0;
-        } else {
-            val = e[(size_t)py * g.pitch + px];
+        const size_t off = (size_t)py * g.pitch + px;
+        const bool whole = px + 3 < w;
+        unsigned ev;
+        if (whole) ev = *reinterpret_cast<const unsigned*>(e + off);
+        else { ev = 0; for (int q = 0; q < 4 && px + q < w; q++) ev |= (unsigned)e[off + q] << (8 * q); }
+        unsigned outw = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            unsigned val = (ev >> (8 * q)) & 0xffu;
+            if (best[k][q] >= 0) {
+                const int mx = __float2int_rn(R->circles[best[k][q]][0]), my = __float2int_rn(R->circles[best[k][q]][1]);
+                const bool plus = (px + q == mx && iabs_(py - my) <= 1) || (py == my && iabs_(px + q - mx) <= 1);
+                val = plus ? 255u : 0u;
+            }
+            outw |= val << (8 * q);
+            if (val != 0 && px + q < w) s_nz[atomicAdd(&s_n, 1)] = (unsigned short)(ly * ET_W + lx0 + q);   // non-zero pixels are few: vote on a dense list
         }
-        o[(size_t)py * g.pitch + px] = val;
-        if (val != 0) s_nz[atomicAdd(&s_n, 1)] = (unsigned short)p;      // non-zero pixels are few: vote on a dense list
+        if (whole) *reinterpret_cast<unsigned*>(o + off) = outw;
+        else for (int q = 0; q < 4 && px + q < w; q++) o[off + q] = (uint8_t)(outw >> (8 * q));
     }
     __syncthreads();
     {
