@@ -266,10 +266,23 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
                 const int xmin = s_win[s][0], xmax = s_win[s][1], ymin = s_win[s][2], ymax = s_win[s][3];
                 const int bw = imax(xmax - xmin, 0), bh = imax(ymax - ymin, 0);
                 cnt = bw * bh;
-                for (int i = lane; i < cnt; i += 64) {
-                    const int yy = i / bw, xx = i - yy * bw;
-                    sum += gp0[(size_t)(ymin + yy) * g.pitch + xmin + xx];
-                }
+                // 4 pixels per lane (one unaligned dword, bytes beyond the window masked off, v_sad_u8 adds the four bytes),
+                // L lanes per row, 64 / L rows per step; a dword may reach 3 bytes past the window, never past the plane's
+                // allocation (rows are padded to the pitch, the plane array ends with slack)
+                const int L = imin(64, (bw + 3) >> 2);
+                const int rows_per = 64 / imax(L, 1);
+                const int ry = lane / imax(L, 1), lx = lane - ry * L;
+                if (bw > 0 && ry < rows_per)
+                    for (int yy = ry; yy < bh; yy += rows_per) {
+                        const uint8_t* row = gp0 + (size_t)(ymin + yy) * g.pitch + xmin;
+                        for (int xx = 4 * lx; xx < bw; xx += 4 * L) {
+                            unsigned v4;
+                            __builtin_memcpy(&v4, row + xx, 4);
+                            const int nvalid = bw - xx;                       // >= 1
+                            if (nvalid < 4) v4 &= (1u << (8 * nvalid)) - 1u;
+                            sum = __builtin_amdgcn_sad_u8(v4, 0u, sum);
+                        }
+                    }
             }
             for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
             if (s < ns && lane == 0) {

@@ -132,6 +132,15 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
 }
 static inline int __float_as_int(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
+// v_sad_u8: sum of absolute differences of the four bytes of a and b, plus c
+static inline unsigned __builtin_amdgcn_sad_u8(unsigned a, unsigned b, unsigned c)
+{
+    for (int i = 0; i < 4; i++) {
+        const int x = (int)((a >> (8 * i)) & 0xffu), y = (int)((b >> (8 * i)) & 0xffu);
+        c += (unsigned)(x > y ? x - y : y - x);
+    }
+    return c;
+}
 static inline int __mul24(int a, int b) { return a * b; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }
