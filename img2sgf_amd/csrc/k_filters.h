@@ -28,13 +28,13 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
     int cb, cg, cr;
     if (shift == 14) { cb = 1868; cg = 9617; cr = 4899; } else { cb = 3735; cg = 19235; cr = 9798; }
     const int half = 1 << (shift - 1);
-    if (x0 + 3 < im.w && ((reinterpret_cast<size_t>(im.src) | (size_t)im.sstride) & 3) == 0) {
-        // whole dwords (the usual case: numpy / torch rows start 4-byte aligned)
+    if (x0 + 3 < im.w) {
+        // whole dwords; the source may start anywhere (odd-width RGB rows): the loads are unaligned dword loads
         unsigned out;
-        if (im.cn == 1) out = *reinterpret_cast<const unsigned*>(s + x0);
+        if (im.cn == 1) __builtin_memcpy(&out, s + x0, 4);
         else {
-            const unsigned* s3 = reinterpret_cast<const unsigned*>(s + 3 * x0);
-            const unsigned d0 = s3[0], d1 = s3[1], d2 = s3[2];            // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+            unsigned d0, d1, d2;                                          // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+            __builtin_memcpy(&d0, s + 3 * x0, 4); __builtin_memcpy(&d1, s + 3 * x0 + 4, 4); __builtin_memcpy(&d2, s + 3 * x0 + 8, 4);
             const unsigned g0 = ((d0 & 0xffu) * cb + ((d0 >> 8) & 0xffu) * cg + ((d0 >> 16) & 0xffu) * cr + half) >> shift;
             const unsigned g1 = ((d0 >> 24) * cb + (d1 & 0xffu) * cg + ((d1 >> 8) & 0xffu) * cr + half) >> shift;
             const unsigned g2 = (((d1 >> 16) & 0xffu) * cb + (d1 >> 24) * cg + (d2 & 0xffu) * cr + half) >> shift;
