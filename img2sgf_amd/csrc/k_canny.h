@@ -296,28 +296,39 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     }   // tiles of the group
 }
 
-// One hysteresis pass over the tiles of a worklist (all maps of the phase).  A fixed, small grid of workgroups strides
-// over the list; each listed 64x32 tile (with a read-only 1-px apron) is brought to a local fixed point in LDS.  The host
-// launches passes back to back; a pass returns at once when the previous pass changed nothing anywhere
+// One hysteresis pass over the tiles of a worklist (all maps of the phase).  A fixed, small grid of workgroups strides over
+// the list, one WAVEFRONT per listed 64x32 tile: lane r holds row y0 - 1 + r of the tile (rows -1 and 32 are the read-only
+// apron) as two 64-bit masks, S (edge) and W (weak candidate).  One step of "a weak pixel becomes an edge iff an 8-neighbour
+// is an edge" is then a handful of 64-bit operations for the whole tile: neighbours in the row are shifts, rows above / below
+// come from the neighbouring lanes, and a row is flooded along its weak runs at once by a carry chain
+// (((M + S) ^ M) & M, M = W | S, in both bit orders).  The tile reaches its local fixed point in as many steps as its
+// longest chain spans ROWS, with no workgroup barrier and no LDS -- scans of photographs, whose contours wander across
+// whole tiles, spent a third of their GPU time in the previous byte-per-thread version (up to 300 us per launch).
+// The host launches passes back to back; a pass returns at once when the previous pass changed nothing anywhere
 // (flags[pass-1] == 0), and from pass 1 on a tile is revisited only if it or one of its 8 neighbours changed in the previous
-// pass (chg[tile] == index of the last pass that changed it, + 1).  The result is the unique fixed point of "a weak pixel
-// becomes an edge iff an 8-neighbour is an edge", independent of scheduling and of the list order.
+// pass (chg[tile] == index of the last pass that changed it, + 1).  The result is the unique fixed point, independent of
+// scheduling and of the list order.
 // maps points at map 0; map m of image b at (m * nb + b) * slot.  `edges` (non-null for the main Canny's phase, whose worklist
-// holds map-0 tiles only) receives 255 / 0 for every rewritten tile: together with the NMS kernel's output that is the edge
-// image of img2sgf.py:162.  grid (HY_BLOCKS), block 256.
+// holds map-0 tiles only) receives 255 / 0 for every rewritten dword: together with the NMS kernel's output that is the edge
+// image of img2sgf.py:162.  grid (HY_BLOCKS), block 256 = 4 independent wavefronts.
 constexpr int HY_BLOCKS = 2048;
+
+// bit i of the result = (byte i of v == 2), i = 0..3 / (byte i of v == 0)
+__device__ __forceinline__ unsigned hy_nib_edge(unsigned v) { return ((((v >> 1) & ~v) & 0x01010101u) * 0x01020408u) >> 24; }
+__device__ __forceinline__ unsigned hy_nib_weak(unsigned v) { return ((~(v | (v >> 1)) & 0x01010101u) * 0x01020408u) >> 24; }
+
+// flood the seeds S along the runs of M (S subset of M) towards higher bits
+__device__ __forceinline__ unsigned long long hy_fill_up(unsigned long long S, unsigned long long M) { return (((M + S) ^ M) & M) | S; }
+
 __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
                                                     uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
                                                     const int* __restrict__ wl, int* __restrict__ chg)
 {
-    constexpr int SROWS = CT_H + 2, SWORDS = CT_W / 4 + 2, SSTR = SWORDS + 1;    // bytes x0-4 .. x0+68, rows y0-1 .. y0+32
-    __shared__ unsigned s_w[SROWS * SSTR];
-    __shared__ int s_flag[2];
-    __shared__ int s_go;
+    static_assert(CT_W == 64 && CT_H + 2 <= 64, "one 64-bit mask per row, one lane per row incl. the apron");
     if (pass > 0 && flags[pass - 1] == 0) return;
     const int nwl = wl[0];
-    const int tid = threadIdx.x;
-    for (int e = blockIdx.x; e < nwl; e += gridDim.x) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int e = blockIdx.x * 4 + wave; e < nwl; e += gridDim.x * 4) {
         const int key = wl[1 + e];
         const int mb = key / g.tiles, tile = key - mb * g.tiles;       // mb = m * nb + b
         const int b = mb % g.nb;
@@ -326,71 +337,88 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
         const int x0 = tx_ * CT_W, y0 = ty_ * CT_H;
         const size_t tbase = (size_t)mb * g.tiles;
         if (pass > 0) {
-            // one thread decides (the stamps may be changing under us; the decision must be uniform across the workgroup
-            // because the tile body contains barriers)
-            __syncthreads();
-            if (tid == 0) {
+            // revisit only if this tile or one of its 8 neighbours changed in the previous pass (lane k looks at neighbour k)
+            bool hit = false;
+            if (lane < 9) {
                 const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
-                int any = 0;
-                for (int dy = -1; dy <= 1; dy++)
-                    for (int dx = -1; dx <= 1; dx++) {
-                        const int tx = tx_ + dx, ty = ty_ + dy;
-                        if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty && chg[tbase + ty * g.tw + tx] == pass) any = 1;
-                    }
-                s_go = any;
+                const int tx = tx_ + lane % 3 - 1, ty = ty_ + lane / 3 - 1;
+                hit = tx >= 0 && tx < ntx && ty >= 0 && ty < nty && chg[tbase + ty * g.tw + tx] == pass;
             }
-            __syncthreads();
-            if (!s_go) continue;
+            if (__ballot(hit) == 0ull) continue;
         }
         uint8_t* mp = maps + (size_t)mb * g.slot;
-        __syncthreads();                                   // previous tile's LDS traffic is over
-        if (tid < 2) s_flag[tid] = 0;
-        load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_ONE>(s_w, mp, g.pitch, w, h, x0 - 4, y0 - 1, tid);
-        __syncthreads();
-        uint8_t* s_map = reinterpret_cast<uint8_t*>(s_w);      // byte (row r, column c) at r * 4 * SSTR + c, pixel x0 + c - 4
-        constexpr int BSTR = 4 * SSTR;
-        // thread owns the 4 (wide) x 2 (tall) patch at tile rows py, py+1, byte columns px .. px+3
-        const int py = 1 + (tid / 16) * 2, px = 4 + (tid % 16) * 4;
-        bool any_change = false;
-        for (int iter = 0; iter < CT_W * CT_H; iter++) {
-            bool changed = false;
-            for (int dy = 0; dy < 2; dy++)
-                for (int dx = 0; dx < 4; dx++) {
-                    const int o = (py + dy) * BSTR + px + dx;
-                    if (s_map[o] != 0) continue;
-                    if (s_map[o - BSTR - 1] == 2 || s_map[o - BSTR] == 2 || s_map[o - BSTR + 1] == 2 ||
-                        s_map[o - 1] == 2 || s_map[o + 1] == 2 ||
-                        s_map[o + BSTR - 1] == 2 || s_map[o + BSTR] == 2 || s_map[o + BSTR + 1] == 2) {
-                        s_map[o] = 2;
-                        changed = true;
+        const int y = y0 - 1 + lane;
+        const bool row_in = lane < CT_H + 2 && y >= 0 && y < h;
+        const bool core = row_in && lane >= 1 && lane <= CT_H;
+        uint4 q[4];
+        unsigned left = 0x01010101u, right = 0x01010101u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        if (row_in) {
+            const uint8_t* row = mp + (size_t)y * g.pitch + x0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = *reinterpret_cast<const uint4*>(row + 16 * k);
+            if (x0 > 0) left = *reinterpret_cast<const unsigned*>(row - 4);
+            if (x0 + CT_W < w) right = *reinterpret_cast<const unsigned*>(row + CT_W);
+        }
+        unsigned long long S = 0, W = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                S |= (unsigned long long)hy_nib_edge(d[i]) << (16 * k + 4 * i);
+                W |= (unsigned long long)hy_nib_weak(d[i]) << (16 * k + 4 * i);
+            }
+        }
+        const int ncol = imin(w - x0, CT_W);                               // columns of the tile inside the image
+        const unsigned long long colmask = ncol >= 64 ? ~0ull : ((1ull << ncol) - 1ull);
+        S &= colmask;
+        W = core ? (W & colmask) : 0ull;                                   // apron rows and rows outside the image never change
+        const bool aL = (left >> 24) == 2u, aR = (right & 0xffu) == 2u;    // edge flags of columns x0 - 1 and x0 + 64
+        const unsigned long long S0 = S;
+        const unsigned long long M = W | S;
+        const unsigned long long rM = __brevll(M);
+        const int up = lane > 0 ? lane - 1 : 0, dn = lane < 63 ? lane + 1 : 63;
+        // side columns: a pixel of column 0 (63) also neighbours column -1 (64) of its own and the adjacent rows
+        const int sideL = (aL ? 1 : 0) | (__shfl(aL ? 1 : 0, up)) | (__shfl(aL ? 1 : 0, dn));
+        const int sideR = (aR ? 1 : 0) | (__shfl(aR ? 1 : 0, up)) | (__shfl(aR ? 1 : 0, dn));
+        const unsigned long long side = (sideL ? 1ull : 0ull) | (sideR ? (1ull << 63) : 0ull);
+        for (;;) {
+            // along the row, both directions, to completion (up from the lowest seed of a run, then down from its top)
+            unsigned long long T = hy_fill_up(S, M);
+            T |= __brevll(hy_fill_up(__brevll(T), rM));
+            // one step to the rows above and below (and their diagonals), and from the side columns
+            const unsigned long long a = __shfl(T, up), c = __shfl(T, dn);
+            unsigned long long N = (lane > 0 ? a : 0ull) | (lane < 63 ? c : 0ull);
+            N = N | (N << 1) | (N >> 1) | side;
+            T |= W & N;
+            const bool changed = T != S;
+            S = T;
+            if (__ballot(changed) == 0ull) break;
+        }
+        const unsigned long long promoted = core ? (S & ~S0) : 0ull;
+        if (__ballot(promoted != 0ull) == 0ull) continue;
+        if (promoted) {
+            uint8_t* row = mp + (size_t)y * g.pitch + x0;
+            uint8_t* erow = edges ? edges + (size_t)mb * g.slot + (size_t)y * g.pitch + x0 : nullptr;      // mb == b in the main phase
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const unsigned nib = (unsigned)(promoted >> (16 * k + 4 * i)) & 0xfu;
+                    if (nib) {
+                        // promoted pixels were weak (byte 0): OR-ing 2 in makes them edges; dwords are written whole (columns
+                        // beyond the image inside the pitch padding keep what they held)
+                        const unsigned v = d[i] | (((nib * 0x00204081u) & 0x01010101u) << 1);
+                        *reinterpret_cast<unsigned*>(row + 16 * k + 4 * i) = v;
+                        if (erow) *reinterpret_cast<unsigned*>(erow + 16 * k + 4 * i) = ((v >> 1) & ~v & 0x01010101u) * 0xffu;
                     }
                 }
-            if (changed) { s_flag[iter & 1] = 1; any_change = true; }
-            __syncthreads();
-            const int f = s_flag[iter & 1];
-            __syncthreads();
-            if (tid == 0) s_flag[iter & 1] = 0;
-            if (f == 0) break;
-        }
-        if (any_change) {
-            for (int dy = 0; dy < 2; dy++) {
-                const int gy = y0 + py + dy - 1;
-                if (gy >= h) continue;
-                const int gx = x0 + px - 4;
-                const unsigned v4 = s_w[(py + dy) * SSTR + px / 4];
-                const unsigned e4 = ((v4 >> 1) & 0x01010101u) * 0xffu;
-                uint8_t* ep = edges ? edges + (size_t)mb * g.slot : nullptr;      // mb == b in the main phase
-                if (gx + 3 < w) {
-                    *reinterpret_cast<unsigned*>(mp + (size_t)gy * g.pitch + gx) = v4;
-                    if (ep) *reinterpret_cast<unsigned*>(ep + (size_t)gy * g.pitch + gx) = e4;
-                } else for (int q = 0; q < 4 && gx + q < w; q++) {
-                    mp[(size_t)gy * g.pitch + gx + q] = (uint8_t)(v4 >> (8 * q));
-                    if (ep) ep[(size_t)gy * g.pitch + gx + q] = (uint8_t)(e4 >> (8 * q));
-                }
             }
-            flags[pass] = 1;
-            chg[tbase + tile] = pass + 1;
         }
+        if (lane == 0) { flags[pass] = 1; chg[tbase + tile] = pass + 1; }
     }
 }
 

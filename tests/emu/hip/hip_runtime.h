@@ -104,6 +104,12 @@ static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, 
 static inline void __builtin_amdgcn_wave_barrier() { unsigned long long a[64], m; hipemu::wave_exchange(0, a, &m); }
 static inline int __lane_id() { return hipemu::cur->lane; }
 
+static inline unsigned long long __brevll(unsigned long long v)
+{
+    unsigned long long r = 0;
+    for (int i = 0; i < 64; i++) r |= ((v >> i) & 1ull) << (63 - i);
+    return r;
+}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
