@@ -36,7 +36,7 @@ def blur_bank(grey, edges, compat):
 
 
 def process_image(img, threshold=None, black_thr=128, alignment=(glue.LEFT, glue.TOP),
-                  compat=None, keep_planes=True, canny=(50, 200)):
+                  compat=None, keep_planes=True, canny=(50, 200), hc=(10, 100, 30, 1, 30)):
     """img: HxW (grey) or HxWx3 (RGB as the reference holds it) uint8, i.e. the array
     `input_image_np` of img2sgf.py:150.  Returns a dict with every value the reference
     leaves in its globals after process_image()/find_grid()."""
@@ -52,7 +52,7 @@ def process_image(img, threshold=None, black_thr=128, alignment=(glue.LEFT, glue
     per_variant = []
     circles = np.zeros((0, 3), np.float32)
     for b in blurs:                                                    # :179-186
-        c = cvo.hough_circles(b, 10, 100, 30, 1, 30)
+        c = cvo.hough_circles(b, *hc)                                  # (10, 100, 30, 1, 30) in the reference
         per_variant.append(c)
         if len(c) > 0:
             circles = np.vstack((circles, c))

@@ -1,0 +1,100 @@
+"""Differential fuzzing of the HIP path against the oracle: random image kinds (noise, smooth shapes, synthetic diagrams,
+crops of the reference's scans), ragged sizes from 1x1 up, mixed grey / colour batches and random NON-default parameters
+(Canny thresholds, HoughCircles arguments, Hough-lines threshold, black threshold, alignment).  Everything the Detection
+carries and every plane of the last device pass must match bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import parity
+from helpers import GOLDEN
+from img2sgf_amd import synth
+from img2sgf_amd.pipeline import Detector, Params
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+
+_SCANS = {}
+
+
+def _scan(name):
+    if name not in _SCANS:
+        _SCANS[name] = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", name))
+    return _SCANS[name]
+
+
+def _random_image(rng):
+    kind = rng.integers(0, 6)
+    h, w = int(rng.integers(1, 330)), int(rng.integers(1, 330))
+    if kind == 0:                                       # uniform noise, sometimes tiny
+        if rng.random() < 0.3:
+            h, w = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == 1:                                     # smooth ramps + discs + bars
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = ((xx * rng.uniform(0, 1.5) + yy * rng.uniform(0, 1.5)) % 256).astype(np.float64)
+        for _ in range(int(rng.integers(1, 8))):
+            cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(3, 30)
+            img[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = rng.integers(0, 256)
+        for _ in range(int(rng.integers(0, 6))):
+            if rng.random() < 0.5:
+                img[:, int(rng.integers(0, w)):][:, :2] = rng.integers(0, 256)
+            else:
+                img[int(rng.integers(0, h)):][:2, :] = rng.integers(0, 256)
+        img = np.clip(img, 0, 255).astype(np.uint8)
+    elif kind in (2, 3):                                # synthetic diagram, cropped / padded, maybe noisy
+        base = synth.synth_diagram(int(rng.integers(0, 1000)), noisy=kind == 3, geom=synth.GEOM_SMALL)[0]
+        y0, x0 = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        img = np.ascontiguousarray(base[y0:y0 + max(h, 60), x0:x0 + max(w, 60)])
+    else:                                               # window of a reference scan (RGB)
+        src = _scan("ex%d.jpg" % int(rng.integers(1, 18)))
+        sh, sw = src.shape[:2]
+        hh, ww = min(h + 40, sh), min(w + 40, sw)
+        y0, x0 = int(rng.integers(0, sh - hh + 1)), int(rng.integers(0, sw - ww + 1))
+        img = np.ascontiguousarray(src[y0:y0 + hh, x0:x0 + ww])
+    if img.ndim == 2 and rng.random() < 0.25:           # grey content as a 3-channel image with unequal channels
+        img = np.ascontiguousarray(np.stack([img, img[::-1], np.roll(img, 3, axis=1)], axis=-1))
+    return img
+
+
+def _random_params(rng):
+    if rng.random() < 0.35:
+        return Params(), {}
+    lo = int(rng.integers(5, 120))
+    hi = lo + int(rng.integers(0, 200))
+    p1 = int(rng.integers(20, 200))
+    hc = (float(rng.choice([4.0, 10.0, 17.5])), p1, int(rng.integers(15, 60)), int(rng.integers(0, 6)), int(rng.integers(8, 31)))
+    thr = int(rng.integers(20, 140))
+    black = int(rng.integers(40, 220))
+    align = (2 + int(rng.integers(0, 2)), int(rng.integers(0, 2)))      # (LEFT | RIGHT, TOP | BOTTOM), img2sgf.py:86-87
+    p = Params(canny_lo=lo, canny_hi=hi, hc_min_dist=hc[0], hc_param1=hc[1], hc_param2=hc[2], hc_min_radius=hc[3],
+               hc_max_radius=hc[4], line_threshold=thr, black_threshold=black, alignment=align)
+    return p, dict(canny=(lo, hi), hc=hc, threshold=thr, black_thr=black, alignment=align)
+
+
+N_SEEDS = int(os.environ.get("I2S_FUZZ_SEEDS", 60))       # raise for a longer hunt
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_against_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    imgs = [_random_image(rng) for _ in range(4)]
+    params, okw = _random_params(rng)
+    det = Detector(0, 4, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    dets = det.detect_batch(imgs, params, full=True)
+    over = [k for k, d in enumerate(dets) if d.status == 100]
+    if over:
+        # fixed capacities of the C ABI (include/i2s.h) are reported, never silently truncated: the oracle must agree that one
+        # of them was exceeded (4096 circles per image, 2048 per HoughCircles call, 4096 estimates, 8192 centre candidates)
+        from oracle import cv_oracle as cvo
+        for k in over:
+            ref = opipe.process_image(imgs[k], **okw)
+            worst = max(len(c) for c in ref["circles_per_variant"])
+            dbg = [cvo.hough_circles(b, *okw.get("hc", (10, 100, 30, 1, 30)), debug=True)[1] for b in ref["blurs"]]
+            assert (len(ref["circles_all"]) > 4096 or worst > 2048 or max(len(d["est"]) for d in dbg) > 4096
+                    or max(d["n_centers"] for d in dbg) > 8192), "capacity status without a capacity being exceeded"
+        imgs = [im for k, im in enumerate(imgs) if k not in over]
+    if imgs:
+        parity.run_and_compare(det, imgs, params=params, internals=okw == {}, oracle_kwargs=okw)
+    det.close()
