@@ -71,6 +71,10 @@ struct HoughTrig {        // tables of the three HoughLines calls of find_lines 
 };
 
 // two 16-bit lanes per register: arithmetic on these compiles to the packed v_pk_* instructions
+// byte offset of row y inside a plane slot.  Row indices and pitches are < 2^23 and a slot is < 2^31 bytes, so the 24-bit
+// multiply (full rate; a 64-bit (size_t) y * pitch compiles to the quarter-rate v_mad_i64_i32) is exact.
+__device__ __forceinline__ int rowoff(int y, int pitch) { return __mul24(y, pitch); }
+
 typedef short v2s __attribute__((vector_size(4)));
 __device__ __forceinline__ v2s pk_from(unsigned u) { v2s r; __builtin_memcpy(&r, &u, 4); return r; }
 __device__ __forceinline__ unsigned pk_bits(v2s v) { unsigned u; __builtin_memcpy(&u, &v, 4); return u; }

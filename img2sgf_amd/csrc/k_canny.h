@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
                 outw0 |= o0 << (8 * q);
             }
         }
-        const size_t off = (size_t)gy * g.pitch + gx0;
+        const int off = rowoff(gy, g.pitch) + gx0;
         const unsigned outm = mp0 ? outw0 : outw;                        // the word that is the main Canny's map
         const unsigned edgw = ((outm >> 1) & 0x01010101u) * 0xffu;       // 255 where that byte is 2
         bool wk, wk0 = false;
@@ -313,9 +313,14 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
 // image of img2sgf.py:162.  grid (HY_BLOCKS), block 256 = 4 independent wavefronts.
 constexpr int HY_BLOCKS = 2048;
 
-// bit i of the result = (byte i of v == 2), i = 0..3 / (byte i of v == 0)
-__device__ __forceinline__ unsigned hy_nib_edge(unsigned v) { return ((((v >> 1) & ~v) & 0x01010101u) * 0x01020408u) >> 24; }
-__device__ __forceinline__ unsigned hy_nib_weak(unsigned v) { return ((~(v | (v >> 1)) & 0x01010101u) * 0x01020408u) >> 24; }
+// flag bytes (0 / 1): byte i of v == 2, byte i of v == 0 (map bytes are 0, 1 or 2)
+__device__ __forceinline__ unsigned hy_flag_edge(unsigned v) { return (v >> 1) & ~v & 0x01010101u; }
+__device__ __forceinline__ unsigned hy_flag_weak(unsigned v) { return ~(v | (v >> 1)) & 0x01010101u; }
+// 8 mask bits from the flag bytes of two dwords: a byte-wise dot product with the bit weights (v_dot4_u32_u8)
+__device__ __forceinline__ unsigned hy_bits8(unsigned f_lo, unsigned f_hi)
+{
+    return __builtin_amdgcn_udot4(f_hi, 0x80402010u, __builtin_amdgcn_udot4(f_lo, 0x08040201u, 0u, false), false);
+}
 
 // flood the seeds S along the runs of M (S subset of M) towards higher bits
 __device__ __forceinline__ unsigned long long hy_fill_up(unsigned long long S, unsigned long long M) { return (((M + S) ^ M) & M) | S; }
@@ -355,22 +360,23 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; k++) q[k] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
         if (row_in) {
-            const uint8_t* row = mp + (size_t)y * g.pitch + x0;
+            const uint8_t* row = mp + rowoff(y, g.pitch) + x0;
 #pragma unroll
             for (int k = 0; k < 4; k++) q[k] = *reinterpret_cast<const uint4*>(row + 16 * k);
             if (x0 > 0) left = *reinterpret_cast<const unsigned*>(row - 4);
             if (x0 + CT_W < w) right = *reinterpret_cast<const unsigned*>(row + CT_W);
         }
-        unsigned long long S = 0, W = 0;
+        unsigned s_lo = 0, s_hi = 0, w_lo = 0, w_hi = 0;                   // 32 columns each
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                S |= (unsigned long long)hy_nib_edge(d[i]) << (16 * k + 4 * i);
-                W |= (unsigned long long)hy_nib_weak(d[i]) << (16 * k + 4 * i);
-            }
+            const unsigned e01 = hy_bits8(hy_flag_edge(q[k].x), hy_flag_edge(q[k].y)), e23 = hy_bits8(hy_flag_edge(q[k].z), hy_flag_edge(q[k].w));
+            const unsigned k01 = hy_bits8(hy_flag_weak(q[k].x), hy_flag_weak(q[k].y)), k23 = hy_bits8(hy_flag_weak(q[k].z), hy_flag_weak(q[k].w));
+            const unsigned e16 = e01 | (e23 << 8), k16 = k01 | (k23 << 8);   // columns 16 k .. 16 k + 15
+            if (k < 2) { s_lo |= e16 << (16 * k); w_lo |= k16 << (16 * k); }
+            else { s_hi |= e16 << (16 * (k - 2)); w_hi |= k16 << (16 * (k - 2)); }
         }
+        unsigned long long S = (unsigned long long)s_lo | ((unsigned long long)s_hi << 32);
+        unsigned long long W = (unsigned long long)w_lo | ((unsigned long long)w_hi << 32);
         const int ncol = imin(w - x0, CT_W);                               // columns of the tile inside the image
         const unsigned long long colmask = ncol >= 64 ? ~0ull : ((1ull << ncol) - 1ull);
         S &= colmask;
@@ -400,8 +406,8 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
         const unsigned long long promoted = core ? (S & ~S0) : 0ull;
         if (__ballot(promoted != 0ull) == 0ull) continue;
         if (promoted) {
-            uint8_t* row = mp + (size_t)y * g.pitch + x0;
-            uint8_t* erow = edges ? edges + (size_t)mb * g.slot + (size_t)y * g.pitch + x0 : nullptr;      // mb == b in the main phase
+            uint8_t* row = mp + rowoff(y, g.pitch) + x0;
+            uint8_t* erow = edges ? edges + (size_t)mb * g.slot + rowoff(y, g.pitch) + x0 : nullptr;      // mb == b in the main phase
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const unsigned d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         const int ly = ly0 + 16 * k;
         const int px = x0 + lx0, py = y0 + ly;
         if (px >= w || py >= h) continue;
-        const size_t off = (size_t)py * g.pitch + px;
+        const int off = rowoff(py, g.pitch) + px;
         const bool whole = px + 3 < w;
         unsigned ev;
         if (whole) ev = *reinterpret_cast<const unsigned*>(e + off);

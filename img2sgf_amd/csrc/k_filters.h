@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
     const int x0 = (t.tx * 64 + threadIdx.x) * 4;
     if (y >= im.h || x0 >= im.w) return;
     const uint8_t* s = im.src + (size_t)y * im.sstride;
-    uint8_t* o = grey + (size_t)b * g.slot + (size_t)y * g.pitch;
+    uint8_t* o = grey + (size_t)b * g.slot + rowoff(y, g.pitch);
     int cb, cg, cr;
     if (shift == 14) { cb = 1868; cg = 9617; cr = 4899; } else { cb = 3735; cg = 19235; cr = 9798; }
     const int half = 1 << (shift - 1);
@@ -77,7 +77,7 @@ __device__ __forceinline__ void gauss_on_tile(const unsigned* __restrict__ s_src
         for (int q = 0; q < 4; q++) {
             unsigned acc = 0;
 #pragma unroll
-            for (int j = 0; j < K; j++) acc += (unsigned)taps.k[j] * (unsigned)p[4 + q - R + j];
+            for (int j = 0; j < K; j++) acc += __umul24((unsigned)taps.k[j], (unsigned)p[4 + q - R + j]);   // 24-bit multiply: full rate
             t[q] = acc > 65535u ? 65535u : acc;
         }
         s_h[ry * GA_HSTR + 2 * s] = t[0] | (t[1] << 16);
@@ -91,14 +91,15 @@ __device__ __forceinline__ void gauss_on_tile(const unsigned* __restrict__ s_src
         for (int j = 0; j < K; j++) {
             const unsigned h0 = s_h[(ly + j) * GA_HSTR + 2 * s], h1 = s_h[(ly + j) * GA_HSTR + 2 * s + 1];
             const unsigned tj = (unsigned)taps.k[j];
-            a[0] += tj * (h0 & 0xffffu); a[1] += tj * (h0 >> 16); a[2] += tj * (h1 & 0xffffu); a[3] += tj * (h1 >> 16);
+            a[0] += __umul24(tj, h0 & 0xffffu); a[1] += __umul24(tj, h0 >> 16);       // taps <= 256, sums <= 65535
+            a[2] += __umul24(tj, h1 & 0xffffu); a[3] += __umul24(tj, h1 >> 16);
         }
         unsigned ow = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) { const unsigned vv = (a[q] + 32768u) >> 16; ow |= (vv > 255u ? 255u : vv) << (8 * q); }
         const int x = x0 + 4 * s, y = y0 + ly;
         if (y < h && x < w) {
-            uint8_t* dp = o + (size_t)y * pitch + x;
+            uint8_t* dp = o + rowoff(y, pitch) + x;
             if (x + 3 < w) *reinterpret_cast<unsigned*>(dp) = ow;
             else for (int q = 0; q < 4 && x + q < w; q++) dp[q] = (uint8_t)(ow >> (8 * q));
         }
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ des
             const int c = imin3(hi[q], hi[q + 1], hi[q + 2]);
             ow |= (unsigned)imed3(a, m, c) << (8 * q);
         }
-        uint8_t* dp = o + (size_t)y * g.pitch + x;
+        uint8_t* dp = o + rowoff(y, g.pitch) + x;
         if (x + 3 < w) *reinterpret_cast<unsigned*>(dp) = ow;
         else for (int q = 0; q < 4 && x + q < w; q++) dp[q] = (uint8_t)(ow >> (8 * q));
     }
@@ -283,11 +284,11 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
                 }
                 const int x = x0 + c;
                 if (x + 1 < w) {
-                    *reinterpret_cast<unsigned short*>(o5 + (size_t)y * g.pitch + x) = (unsigned short)(m5[0] | (m5[1] << 8));
-                    *reinterpret_cast<unsigned short*>(o7 + (size_t)y * g.pitch + x) = (unsigned short)(m7[0] | (m7[1] << 8));
+                    *reinterpret_cast<unsigned short*>(o5 + rowoff(y, g.pitch) + x) = (unsigned short)(m5[0] | (m5[1] << 8));
+                    *reinterpret_cast<unsigned short*>(o7 + rowoff(y, g.pitch) + x) = (unsigned short)(m7[0] | (m7[1] << 8));
                 } else {
-                    o5[(size_t)y * g.pitch + x] = (uint8_t)m5[0];
-                    o7[(size_t)y * g.pitch + x] = (uint8_t)m7[0];
+                    o5[rowoff(y, g.pitch) + x] = (uint8_t)m5[0];
+                    o7[rowoff(y, g.pitch) + x] = (uint8_t)m7[0];
                 }
             }
         }

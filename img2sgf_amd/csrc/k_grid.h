@@ -274,7 +274,7 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
                 const int ry = lane / imax(L, 1), lx = lane - ry * L;
                 if (bw > 0 && ry < rows_per)
                     for (int yy = ry; yy < bh; yy += rows_per) {
-                        const uint8_t* row = gp0 + (size_t)(ymin + yy) * g.pitch + xmin;
+                        const uint8_t* row = gp0 + rowoff(ymin + yy, g.pitch) + xmin;
                         for (int xx = 4 * lx; xx < bw; xx += 4 * L) {
                             unsigned v4;
                             __builtin_memcpy(&v4, row + xx, 4);

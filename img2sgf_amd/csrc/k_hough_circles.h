@@ -27,9 +27,9 @@ __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitc
 {
     const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
     const int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
-    const uint8_t* r0 = p + (size_t)ym * pitch;
-    const uint8_t* r1 = p + (size_t)y * pitch;
-    const uint8_t* r2 = p + (size_t)yp * pitch;
+    const uint8_t* r0 = p + rowoff(ym, pitch);
+    const uint8_t* r1 = p + rowoff(y, pitch);
+    const uint8_t* r2 = p + rowoff(yp, pitch);
     const int a = r0[xm], b = r0[x], c = r0[xp], d = r1[xm], f = r1[xp], gg = r2[xm], hh = r2[x], ii = r2[xp];
     dx = (c + 2 * f + ii) - (a + 2 * d + gg);
     dy = (gg + 2 * hh + ii) - (a + 2 * b + c);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
         for (int r = 0; r < EBB_Y; r++) {
             const int y = y0 + ly + r * EB;
             m16[r] = make_uint4(0u, 0u, 0u, 0u);
-            if (y < h && xs < w) m16[r] = *reinterpret_cast<const uint4*>(map + (size_t)y * g.pitch + xs);
+            if (y < h && xs < w) m16[r] = *reinterpret_cast<const uint4*>(map + rowoff(y, g.pitch) + xs);
         }
 #pragma unroll
         for (int r = 0; r < EBB_Y; r++) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
         int dx, dy;
         if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2) {
             // interior pixel: the 3x3 neighbourhood as three (unaligned) dword loads instead of eight byte loads
-            const uint8_t* pc = plane + (size_t)y * g.pitch + (x - 1);
+            const uint8_t* pc = plane + rowoff(y, g.pitch) + (x - 1);
             unsigned r0, r1, r2;
             __builtin_memcpy(&r0, pc - g.pitch, 4);
             __builtin_memcpy(&r1, pc, 4);

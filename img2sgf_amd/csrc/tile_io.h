@@ -28,7 +28,7 @@ __device__ __forceinline__ void load_tile_words(unsigned* __restrict__ dst, cons
             const int gy1 = ya + r;
             unsigned v1 = 0x01010101u;
             if (gy1 >= 0 && gy1 < h) {
-                const uint8_t* row1 = plane + (size_t)gy1 * pitch;
+                const uint8_t* row1 = plane + rowoff(gy1, pitch);
                 if (x >= 0 && x + 3 < w) v1 = *reinterpret_cast<const unsigned*>(row1 + x);
                 else {
                     v1 = 0;
@@ -39,7 +39,7 @@ __device__ __forceinline__ void load_tile_words(unsigned* __restrict__ dst, cons
             continue;
         }
         const int gy = border_idx<MODE>(ya + r, h);
-        const uint8_t* row = plane + (size_t)gy * pitch;
+        const uint8_t* row = plane + rowoff(gy, pitch);
         unsigned v;
         if (x >= 0 && x + 3 < w) {
             v = *reinterpret_cast<const unsigned*>(row + x);
@@ -66,7 +66,7 @@ struct TileRegs {
                 const int r = i / WORDS, c = i - r * WORDS;
                 const int gy = border_idx<MODE>(ya + r, h);
                 const int x = xa + 4 * c;
-                const uint8_t* row = plane + (size_t)gy * pitch;
+                const uint8_t* row = plane + rowoff(gy, pitch);
                 if (x >= 0 && x + 3 < w) val = *reinterpret_cast<const unsigned*>(row + x);
                 else val = (unsigned)row[border_idx<MODE>(x, w)] | ((unsigned)row[border_idx<MODE>(x + 1, w)] << 8) |
                            ((unsigned)row[border_idx<MODE>(x + 2, w)] << 16) | ((unsigned)row[border_idx<MODE>(x + 3, w)] << 24);

@@ -147,6 +147,12 @@ static inline unsigned __builtin_amdgcn_sad_u8(unsigned a, unsigned b, unsigned 
     }
     return c;
 }
+// v_dot4_u32_u8: byte-wise dot product of a and b, plus c
+static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool)
+{
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+    return c;
+}
 static inline int __mul24(int a, int b) { return a * b; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }
