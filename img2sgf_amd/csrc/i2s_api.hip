@@ -387,9 +387,15 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         if (rc) return rc;
         hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
                            ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
-        hipLaunchKernelGGL(k_vote_centres, dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
-                           ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
-                           ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+        // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
+        if (p->hc_max_radius - p->hc_min_radius + 1 == 30)
+            hipLaunchKernelGGL((k_vote_centres<30>), dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
+                               ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                               ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+        else
+            hipLaunchKernelGGL((k_vote_centres<0>), dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
+                               ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                               ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
         hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                            ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
                            ctx->d_est_keys, est_count(ctx));

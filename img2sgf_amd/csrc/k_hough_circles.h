@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
 // the first valid cell of the tile, with (sx, sy) negated for the second direction.  Cells outside [0, vx_n) x [0, vy_n)
 // (outside the image or the tile) are skipped, which equals OpenCV's "break at the first cell outside the image" because a
 // ray leaves the convex image only once.
+template <int NSTEPS>   // > 0: the number of radius steps is known at compile time (the loop is unrolled); 0: use `nsteps`
 __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, int count, int lane,
                                             const uint2* __restrict__ bin_ent, int vx_lo, int vy_lo,
                                             unsigned vx_n, unsigned vy_n, int offx, int offy, int min_r, int nsteps,
@@ -152,13 +153,19 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
         x = (((int)(e.x & 0xffffu) - vx_lo) << 10) + min_r * sx;
         y = (((int)(e.x >> 16) - vy_lo) << 10) + min_r * sy;
     }
-    for (int st = 0; st < nsteps; st++) {
+    auto step = [&]() {
         const unsigned tx = (unsigned)(x >> 10), ty = (unsigned)(y >> 10);
         if (tx < vx_n && ty < vy_n) {
             const unsigned cy = ty + (unsigned)offy;
             atomicAdd(&s_acc[(cy & 63u) * (unsigned)VASTR + tx + (unsigned)offx], (cy & 64u) ? 0x10000u : 1u);
         }
         x += sx; y += sy;
+    };
+    if (NSTEPS > 0) {
+#pragma unroll
+        for (int st = 0; st < NSTEPS; st++) step();
+    } else {
+        for (int st = 0; st < nsteps; st++) step();
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -178,6 +185,7 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
 // (same-address LDS atomics serialise, ~4 cycles per extra lane: profiles/r01_g_lds_atomic_microbench.txt).
 // (Measured: plain 32-bit cells halve the resident workgroups per CU and run 1.5x slower; a branch-free variant that
 // lets out-of-tile lanes add 0 to clamped cells runs 1.4x slower because of same-address conflicts.)
+template <int NSTEPS>
 __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict__ desc, Geo g,
                                                       const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
                                                       int min_r, int max_r, int acc_thr,
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
             fill += __popcll(mn);
             __builtin_amdgcn_wave_barrier();
             while (fill >= 64) {
-                vote_walk64(ring, 64, lane, bin_ent, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+                vote_walk64<NSTEPS>(ring, 64, lane, bin_ent, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
                 // move the remainder (< 128 items) to the front
                 const int rem = fill - 64;
                 unsigned t0 = 0, t1 = 0;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
         }
         q = qn; n_cur = n_next; ent_cur = ent_next; mine = mine_next;
     }
-    if (fill > 0) vote_walk64(ring, fill, lane, bin_ent, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+    if (fill > 0) vote_walk64<NSTEPS>(ring, fill, lane, bin_ent, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
     __syncthreads();
     // centre candidates: cells (x,y), 1 <= x <= w-1, 1 <= y <= h-1 (OpenCV scans padded rows 1..H, cols 1..W
     // of an accumulator whose votes sit at unpadded indices; cells x == W or y == H hold no votes).
