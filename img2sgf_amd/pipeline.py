@@ -173,7 +173,13 @@ class Detector:
             rc = self.lib.dll.i2s_detect_batch_xf(self._ctx, B, arr_p, mk(ws), mk(hs), mk(strides), mk(chans), xf,
                                                   C.byref(p), boards, res)
         self._check(rc)
-        self._last_shapes = shapes[-((B - 1) % self.max_batch + 1):]
+        n_last = (B - 1) % self.max_batch + 1 if B else 0
+        if params.schedule and B > self.max_batch:
+            # the C side formed its passes over the images sorted by area (stable): the last pass holds the largest ones
+            order = sorted(range(B), key=lambda i: shapes[i][0] * shapes[i][1])
+            self._last_shapes = [shapes[i] for i in order[B - n_last:]]
+        else:
+            self._last_shapes = shapes[B - n_last:]
         return boards, res
 
     def detect_batch(self, images: Sequence[np.ndarray], params: Optional[Params] = None, full=True, xforms=None):

@@ -183,6 +183,11 @@ def test_scheduled_ragged_batch_returns_input_order(lib):
     sched = det.detect_batch(imgs, Params(schedule=True), full=False)
     for k in range(len(imgs)):
         assert bytes(plain[k]) == bytes(sched[k]), k
+    # the resident ("last") pass of a scheduled call holds the largest images, in area order
+    order = sorted(range(len(imgs)), key=lambda i: imgs[i].shape[0] * imgs[i].shape[1])
+    n_last = (len(imgs) - 1) % 3 + 1
+    for j, i in enumerate(order[len(imgs) - n_last:]):
+        np.testing.assert_array_equal(det.fetch_plane(j, "grey"), imgs[i])
     xfs = [preprocess.xform((i.shape[1], i.shape[0]), 2.0 * k, None) for k, i in enumerate(imgs)]
     plain = det.detect_batch(imgs, Params(), full=True, xforms=xfs)
     sched = det.detect_batch(imgs, Params(schedule=True), full=True, xforms=xfs)
