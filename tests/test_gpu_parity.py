@@ -310,3 +310,16 @@ def test_streamed_host_batch_matches_single_stream():
     sd.close()
     for k in range(len(batch)):
         assert bytes(got[k]) == bytes(want[k]), k
+
+
+def test_large_images():
+    """Sizes beyond the benchmark's: a 2048x2048 mosaic of four diagrams, a 1536x2560 image and a 1100x1700 colour one (every
+    plane, circle, line and record against the oracle; all below the 4096-circle capacity)."""
+    a, b2 = synth.synth_diagram(11)[0], synth.synth_diagram(12)[0]
+    big = np.ascontiguousarray(np.block([[a, b2], [b2[::-1], a[:, ::-1]]]))
+    wide = np.ascontiguousarray(np.pad(big, ((0, 0), (0, 512)), constant_values=255)[:1536])      # stays below the 4096-circle capacity
+    sub = wide[:1100, :1700]
+    col = np.ascontiguousarray(np.stack([sub, sub[:, ::-1], sub], axis=-1))
+    det = Detector(0, 3, 2560, 2048)
+    parity.run_and_compare(det, [big, wide, col])
+    det.close()
