@@ -98,3 +98,33 @@ def test_fuzz_against_oracle(seed):
     if imgs:
         parity.run_and_compare(det, imgs, params=params, internals=okw == {}, oracle_kwargs=okw)
     det.close()
+
+
+@pytest.mark.parametrize("seed", range(max(N_SEEDS // 3, 1)))
+def test_fuzz_device_preprocessing_against_pillow(seed):
+    """Random rotate / crop / contrast / brightness on the device against Pillow itself (staged source bit for bit), then the
+    detection against the oracle run on Pillow's result."""
+    from PIL import Image
+    from img2sgf_amd import preprocess
+    rng = np.random.default_rng(5000 + seed)
+    imgs, xfs, wants = [], [], []
+    contrast, brightness = int(rng.integers(0, 101)), int(rng.integers(0, 101))
+    for _ in range(3):
+        img = _random_image(rng)
+        h, w = img.shape[:2]
+        angle = float(rng.choice([0.0, 90.0, 180.0, -90.0])) if rng.random() < 0.3 else float(rng.uniform(-180, 180))
+        if rng.random() < 0.4:
+            sel = None
+        else:
+            x1, y1 = int(rng.integers(-5, max(w // 2, 1))), int(rng.integers(-5, max(h // 2, 1)))
+            sel = (x1, y1, x1 + int(rng.integers(1, w + 8)), y1 + int(rng.integers(1, h + 8)))
+        imgs.append(img)
+        xfs.append(preprocess.xform((w, h), angle, sel))
+        wants.append(preprocess.enhance(Image.fromarray(img), contrast, brightness, rotate_angle=angle, selection=sel))
+    det = Detector(0, 3, max(x[1][2] - x[1][0] for x in xfs), max(x[1][3] - x[1][1] for x in xfs))
+    dets = det.detect_batch(imgs, Params(contrast=contrast, brightness=brightness), xforms=xfs)
+    for k, (img, want, d) in enumerate(zip(imgs, wants, dets)):
+        np.testing.assert_array_equal(det.fetch_source(k, 1 if img.ndim == 2 else 3), want, err_msg="image %d" % k)
+        if d.status != 100:
+            parity.compare_detection(d, opipe.process_image(want))
+    det.close()
