@@ -29,17 +29,41 @@ def main(argv=None):
     if len(inputs) == 2 and inputs[1].lower().endswith(".sgf") and not args.outdir:
         inputs, out_single = inputs[:1], inputs[1]
     import numpy as np
-    images = [np.array(preprocess.load_image(p)) for p in inputs]   # decoded RGB; rotate / crop / contrast / brightness run on the GPU
-    xforms = None
-    if args.rotate != 0 or args.selection:
-        xforms = [preprocess.xform((i.shape[1], i.shape[0]), args.rotate, args.selection) for i in images]
-    out_w = [x[1][2] - x[1][0] for x in xforms] if xforms else [i.shape[1] for i in images]
-    out_h = [x[1][3] - x[1][1] for x in xforms] if xforms else [i.shape[0] for i in images]
-    det = pipeline.Detector(args.device, min(len(images), 16), max(out_w), max(out_h))
     params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
                              contrast=args.contrast, brightness=args.brightness, schedule=True)
+    # Sequential JPEGs are decoded on the GPU straight from the file bytes (bit-exact with Pillow's decoder); anything else
+    # (progressive JPEG, PNG, ...) is opened with Pillow as the reference does (img2sgf.py:651).  Rotate / crop / contrast /
+    # brightness run on the GPU either way.
+    blobs, sizes = {}, []
+    for k, path in enumerate(inputs):
+        with open(path, "rb") as f:
+            data = f.read()
+        try:
+            w, h, _ = pipeline.jpeg_info(data)
+            blobs[k] = data
+        except pipeline.I2sError:
+            im = np.array(preprocess.load_image(path))
+            blobs[k] = im
+            w, h = im.shape[1], im.shape[0]
+        sizes.append((w, h))
+    xforms = None
+    if args.rotate != 0 or args.selection:
+        xforms = [preprocess.xform(sz, args.rotate, args.selection) for sz in sizes]
+    out_w = [x[1][2] - x[1][0] for x in xforms] if xforms else [sz[0] for sz in sizes]
+    out_h = [x[1][3] - x[1][1] for x in xforms] if xforms else [sz[1] for sz in sizes]
+    det = pipeline.Detector(args.device, min(len(inputs), 16), max(out_w), max(out_h))
+    results = [None] * len(inputs)
+    for is_jpeg in (True, False):
+        idx = [k for k in range(len(inputs)) if isinstance(blobs[k], bytes) == is_jpeg]
+        if not idx:
+            continue
+        xf = [xforms[k] for k in idx] if xforms else None
+        items = [blobs[k] for k in idx]
+        dets = det.detect_jpeg(items, params, xforms=xf) if is_jpeg else det.detect_batch(items, params, xforms=xf)
+        for k, d in zip(idx, dets):
+            results[k] = d
     rc = 0
-    for path, d in zip(inputs, det.detect_batch(images, params, xforms=xforms)):
+    for path, d in zip(inputs, results):
         name = os.path.splitext(os.path.basename(path))[0] + ".sgf"
         out = out_single or (os.path.join(args.outdir, name) if args.outdir else None)
         if not d.board_ready:

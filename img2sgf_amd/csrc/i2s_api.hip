@@ -16,7 +16,9 @@
 #include "k_erase_lines.h"
 #include "k_filters.h"
 #include "k_grid.h"
+#include "jpeg_host.h"
 #include "k_hough_circles.h"
+#include "k_jpeg.h"
 #include "k_preprocess.h"
 
 using namespace i2s;
@@ -49,6 +51,10 @@ struct i2s_ctx {
     XfDesc* h_xf = nullptr;
     uint8_t* d_raw = nullptr;    // untransformed host sources of one pass (grown on demand)
     size_t raw_bytes = 0;
+    uint8_t* d_jpg = nullptr;    // JPEG decoding workspace of one pass: coefficients | component planes | RGB images (grown on demand)
+    size_t jpg_bytes = 0;
+    JpgDesc* d_jd = nullptr;     // [max_batch]
+    JpgDesc* h_jd = nullptr;
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
     int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
@@ -128,9 +134,9 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum, ctx->d_xf, ctx->d_raw};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd};
     for (void* q : dev) if (q) (void)hipFree(q);
-    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf};
+    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd};
     for (void* q : host) if (q) (void)hipHostFree(q);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -167,6 +173,8 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipHostMalloc(&ctx->h_desc, nb * sizeof(ImgDesc)));
     I2S_HIP(hipMalloc(&ctx->d_xf, nb * sizeof(XfDesc)));
     I2S_HIP(hipHostMalloc(&ctx->h_xf, nb * sizeof(XfDesc)));
+    I2S_HIP(hipMalloc(&ctx->d_jd, nb * sizeof(JpgDesc)));
+    I2S_HIP(hipHostMalloc(&ctx->h_jd, nb * sizeof(JpgDesc)));
     I2S_HIP(hipMalloc(&ctx->d_flags, 2 * HYST_MAX_PASSES * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_flags, 2 * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * CENT_CAP * sizeof(unsigned)));
@@ -559,6 +567,132 @@ extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, 
                                 i2s_board* boards, i2s_result* full)
 {
     return i2s_detect_batch_xf(ctx, B, img, w, h, stride, channels, nullptr, p, boards, full);
+}
+
+// ---- JPEG input ------------------------------------------------------------------------------------------------
+
+extern "C" int i2s_jpeg_info(const uint8_t* data, size_t len, int* w, int* h, int* channels)
+{
+    if (!data) return I2S_E_INVALID;
+    JpegFile f;
+    const int rc = jpg_parse(data, len, &f);
+    if (rc == JPG_BAD) return I2S_E_INVALID;
+    if (rc == JPG_UNSUPPORTED) return I2S_E_UNSUPPORTED;
+    if (w) *w = f.X;
+    if (h) *h = f.Y;
+    if (channels) *channels = f.ncomp;
+    return I2S_OK;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* jpeg, const size_t* len, const i2s_xform* xf,
+                                     const i2s_params* p, i2s_board* boards, i2s_result* full)
+{
+    if (!ctx || B < 0 || (B > 0 && (!jpeg || !len || !boards))) return I2S_E_INVALID;
+    int rc = check_params(p);
+    if (rc) return rc;
+    std::vector<JpegFile> files(B);
+    for (int i = 0; i < B; i++) {
+        if (!jpeg[i]) return I2S_E_INVALID;
+        const int jr = jpg_parse(jpeg[i], len[i], &files[i]);
+        if (jr == JPG_BAD) return I2S_E_INVALID;
+        if (jr == JPG_UNSUPPORTED) return I2S_E_UNSUPPORTED;
+    }
+    I2S_HIP(hipSetDevice(ctx->device));
+    // pass formation as in i2s_detect_batch_xf (by processed area when p->schedule is set)
+    std::vector<int> order(B);
+    for (int i = 0; i < B; i++) order[i] = i;
+    if (p->schedule && B > ctx->max_batch) {
+        auto area = [&](int i) {
+            return xf ? (long long)(xf[i].crop[2] - xf[i].crop[0]) * (xf[i].crop[3] - xf[i].crop[1]) : (long long)files[i].X * files[i].Y;
+        };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area(a) < area(b); });
+    }
+    i2s_params pd = *p;
+    pd.inputs_on_device = 1;
+    pd.schedule = 0;
+    float timing[5] = {0, 0, 0, 0, 0};
+    std::vector<int16_t> coef;
+    std::vector<i2s_board> pb(ctx->max_batch);
+    std::vector<i2s_result> pf(full ? ctx->max_batch : 0);
+    std::vector<i2s_xform> pxf(xf ? ctx->max_batch : 0);
+    std::vector<const uint8_t*> ptr(ctx->max_batch);
+    std::vector<int> pw(ctx->max_batch), ph(ctx->max_batch), ps(ctx->max_batch), pc(ctx->max_batch, 3);
+    for (int first = 0; first < B; first += ctx->max_batch) {
+        const int nb = B - first < ctx->max_batch ? B - first : ctx->max_batch;
+        // workspace layout of the pass: [coefficients of all images][component planes][RGB images]
+        size_t ncoef = 0, nplane = 0, nrgb = 0;
+        for (int i = 0; i < nb; i++) {
+            const JpegFile& f = files[order[first + i]];
+            for (int c = 0; c < f.ncomp; c++) {
+                ncoef += align256((size_t)f.c[c].bw * f.c[c].bh * 64 * sizeof(int16_t));
+                nplane += align256((size_t)f.c[c].bw * f.c[c].bh * 64);
+            }
+            nrgb += align256((size_t)f.X * f.Y * 3);
+        }
+        const size_t need = ncoef + nplane + nrgb + 256;          // + slack: the classifier's dword loads may reach 3 bytes further
+        if (need > ctx->jpg_bytes) {
+            I2S_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->d_jpg) I2S_HIP(hipFree(ctx->d_jpg));
+            ctx->d_jpg = nullptr; ctx->jpg_bytes = 0;
+            I2S_HIP(hipMalloc(&ctx->d_jpg, need));
+            ctx->jpg_bytes = need;
+        }
+        // entropy decoding on the host, one image after the other, into one coefficient array for the pass
+        coef.assign(ncoef / sizeof(int16_t), 0);
+        size_t co = 0, po = ncoef, ro = ncoef + nplane;
+        int wmax = 0, hmax = 0, max_blocks = 0;
+        for (int i = 0; i < nb; i++) {
+            const int k = order[first + i];
+            const JpegFile& f = files[k];
+            JpgDesc& J = ctx->h_jd[i];
+            int16_t* cp[3] = {nullptr, nullptr, nullptr};
+            int blocks = 0;
+            for (int c = 0; c < 3; c++) {
+                J.coef[c] = nullptr; J.plane[c] = nullptr; J.bw[c] = J.bh[c] = J.dw[c] = J.dh[c] = J.nblocks[c] = 0;
+            }
+            for (int c = 0; c < f.ncomp; c++) {
+                const size_t nblk = (size_t)f.c[c].bw * f.c[c].bh;
+                cp[c] = coef.data() + co / sizeof(int16_t);
+                J.coef[c] = reinterpret_cast<const int16_t*>(ctx->d_jpg + co);
+                J.plane[c] = ctx->d_jpg + po;
+                co += align256(nblk * 64 * sizeof(int16_t));
+                po += align256(nblk * 64);
+                J.bw[c] = f.c[c].bw; J.bh[c] = f.c[c].bh; J.dw[c] = f.c[c].dw; J.dh[c] = f.c[c].dh;
+                J.nblocks[c] = (int)nblk;
+                blocks += (int)nblk;
+                for (int q = 0; q < 64; q++) J.q[c][q] = f.q[f.c[c].tq][q];
+            }
+            if (jpg_decode_scan(f, cp) != JPG_OK) {
+                snprintf(ctx->err, sizeof(ctx->err), "JPEG %d: corrupt entropy-coded data", k);
+                return I2S_E_INVALID;
+            }
+            J.ncomp = f.ncomp; J.X = f.X; J.Y = f.Y; J.hs = f.c[0].h; J.vs = f.c[0].v;
+            J.out = ctx->d_jpg + ro; J.out_stride = f.X * 3;
+            ro += align256((size_t)f.X * f.Y * 3);
+            ptr[i] = J.out; pw[i] = f.X; ph[i] = f.Y; ps[i] = f.X * 3;
+            if (xf) pxf[i] = xf[k];
+            wmax = f.X > wmax ? f.X : wmax; hmax = f.Y > hmax ? f.Y : hmax;
+            max_blocks = blocks > max_blocks ? blocks : max_blocks;
+        }
+        I2S_HIP(hipMemcpyAsync(ctx->d_jpg, coef.data(), ncoef, hipMemcpyHostToDevice, ctx->stream));
+        I2S_HIP(hipMemcpyAsync(ctx->d_jd, ctx->h_jd, nb * sizeof(JpgDesc), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_jpeg_idct, dim3(cdiv(max_blocks, 64), nb), dim3(64), 0, ctx->stream, ctx->d_jd);
+        hipLaunchKernelGGL(k_jpeg_rgb, dim3(cdiv(wmax, 64), cdiv(hmax, 4), nb), dim3(64, 4), 0, ctx->stream, ctx->d_jd);
+        // the decoded images are device-resident sources of the ordinary path
+        rc = i2s_detect_batch_xf(ctx, nb, ptr.data(), pw.data(), ph.data(), ps.data(), pc.data(), xf ? pxf.data() : nullptr, &pd,
+                                 pb.data(), full ? pf.data() : nullptr);
+        if (rc) return rc;
+        for (int i = 0; i < nb; i++) {
+            boards[order[first + i]] = pb[i];
+            if (full) full[order[first + i]] = pf[i];
+        }
+        for (int i = 0; i < 5; i++) timing[i] += ctx->timing[i];
+    }
+    for (int i = 0; i < 5; i++) ctx->timing[i] = timing[i];
+    ctx->last_staged = 1;          // i2s_fetch_source: the decoded (and, if requested, transformed / enhanced) image
+    return I2S_OK;
 }
 
 extern "C" int i2s_classify_batch(i2s_ctx* ctx, int first, int n, const i2s_params* p, i2s_board* boards, i2s_result* full)

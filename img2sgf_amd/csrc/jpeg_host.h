@@ -1,0 +1,272 @@
+// Baseline JPEG front end: marker parsing and Huffman entropy decoding on the host -- a serial bit stream per
+// scan -- into quantised DCT coefficient blocks.  Everything after that (dequantisation, inverse DCT, chroma upsampling,
+// colour conversion: csrc/k_jpeg.h) runs on the device.  The reference reaches the same pixels through
+// PIL.Image.open(path).convert("RGB") (img2sgf.py:651), i.e. libjpeg-turbo with its defaults (JDCT_ISLOW, fancy upsampling);
+// this file and k_jpeg.h restate exactly that decoder for sequential 8-bit Huffman JPEGs (SOF0 / SOF1, one interleaved scan,
+// 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0).  Everything else (progressive, arithmetic coding, multi-scan, CMYK, RGB-coded,
+// 12-bit) is reported as unsupported so that the caller can decode it elsewhere; nothing is approximated.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+namespace i2s {
+
+struct JpegComp {
+    int id, h, v, tq, td, ta;
+    int bw, bh;          // blocks per row / column (padded to whole MCUs)
+    int dw, dh;          // real (downsampled) sample dimensions
+};
+
+struct JpegHuff {
+    bool present = false;
+    uint8_t look_len[512];     // code length for the 9-bit prefix (0 = longer than 9 bits)
+    uint8_t look_sym[512];
+    int maxcode[18];           // largest code of each length (-1 if none), as in jdhuff.c
+    int valoff[17];
+    uint8_t syms[256];
+};
+
+struct JpegFile {
+    int X = 0, Y = 0, ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, dri = 0;
+    JpegComp c[3];
+    uint16_t q[4][64];         // natural (row-major) order
+    bool have_q[4] = {false, false, false, false};
+    JpegHuff dc[4], ac[4];
+    const uint8_t* scan = nullptr;
+    size_t scan_len = 0;
+};
+
+enum { JPG_OK = 0, JPG_BAD = 1, JPG_UNSUPPORTED = 2 };
+
+static const uint8_t JPG_ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                   41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                   30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+static int jpg_build_huff(const uint8_t* counts, const uint8_t* syms, int nsyms, JpegHuff* h)
+{
+    memset(h->look_len, 0, sizeof(h->look_len));
+    memcpy(h->syms, syms, (size_t)nsyms);
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+        h->valoff[l] = k - code;
+        for (int i = 0; i < counts[l - 1]; i++, k++, code++) {
+            if (l <= 9) {
+                const int lo = code << (9 - l), n = 1 << (9 - l);
+                if (lo + n > 512) return JPG_BAD;
+                for (int j = 0; j < n; j++) { h->look_len[lo + j] = (uint8_t)l; h->look_sym[lo + j] = syms[k]; }
+            }
+        }
+        h->maxcode[l] = counts[l - 1] ? code - 1 : -1;
+        if (code > (1 << l)) return JPG_BAD;
+        code <<= 1;
+    }
+    h->maxcode[17] = 0x7fffffff;
+    h->present = true;
+    return JPG_OK;
+}
+
+// Parses the markers up to and including the (single) start of scan.
+static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
+{
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return JPG_BAD;
+    size_t p = 2;
+    bool have_frame = false, adobe_rgb = false;
+    for (;;) {
+        if (p + 4 > n || d[p] != 0xFF) return JPG_BAD;
+        while (p + 1 < n && d[p + 1] == 0xFF) p++;
+        const int m = d[p + 1];
+        p += 2;
+        if (m == 0xD9) return JPG_BAD;                               // EOI before any scan
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;         // parameterless markers
+        if (p + 2 > n) return JPG_BAD;
+        const size_t L = ((size_t)d[p] << 8) | d[p + 1];
+        if (L < 2 || p + L > n) return JPG_BAD;
+        const uint8_t* s = d + p + 2;
+        const size_t sl = L - 2;
+        if (m == 0xDB) {
+            size_t i = 0;
+            while (i < sl) {
+                const int pq = s[i] >> 4, tq = s[i] & 15;
+                i++;
+                if (tq > 3 || pq > 1) return JPG_BAD;
+                if (pq == 1) return JPG_UNSUPPORTED;                 // 16-bit tables belong to 12-bit data
+                if (i + 64 > sl) return JPG_BAD;
+                for (int k = 0; k < 64; k++) f->q[tq][JPG_ZZ[k]] = s[i + k];
+                f->have_q[tq] = true;
+                i += 64;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || have_frame) return JPG_BAD;
+            if (s[0] != 8) return JPG_UNSUPPORTED;
+            f->Y = (s[1] << 8) | s[2]; f->X = (s[3] << 8) | s[4]; f->ncomp = s[5];
+            if (f->X < 1 || f->Y < 1) return JPG_UNSUPPORTED;        // Y == 0 (DNL) is not handled
+            if (f->ncomp != 1 && f->ncomp != 3) return JPG_UNSUPPORTED;
+            if (sl < (size_t)(6 + 3 * f->ncomp)) return JPG_BAD;
+            for (int c = 0; c < f->ncomp; c++) {
+                JpegComp& jc = f->c[c];
+                jc.id = s[6 + 3 * c]; jc.h = s[7 + 3 * c] >> 4; jc.v = s[7 + 3 * c] & 15; jc.tq = s[8 + 3 * c];
+                if (jc.h < 1 || jc.v < 1 || jc.h > 4 || jc.v > 4 || jc.tq > 3) return JPG_BAD;
+            }
+            have_frame = true;
+        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return JPG_UNSUPPORTED;                                  // progressive, lossless, hierarchical, arithmetic
+        } else if (m == 0xCC) {
+            return JPG_UNSUPPORTED;
+        } else if (m == 0xC4) {
+            size_t i = 0;
+            while (i < sl) {
+                const int tc = s[i] >> 4, th = s[i] & 15;
+                i++;
+                if (tc > 1 || th > 3 || i + 16 > sl) return JPG_BAD;
+                int cnt = 0;
+                for (int k = 0; k < 16; k++) cnt += s[i + k];
+                if (cnt > 256 || i + 16 + (size_t)cnt > sl) return JPG_BAD;
+                if (jpg_build_huff(s + i, s + i + 16, cnt, tc ? &f->ac[th] : &f->dc[th])) return JPG_BAD;
+                i += 16 + (size_t)cnt;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) return JPG_BAD;
+            f->dri = (s[0] << 8) | s[1];
+        } else if (m == 0xEE) {
+            // Adobe marker: transform 0 with three components means the data are RGB, not YCbCr
+            if (sl >= 12 && memcmp(s, "Adobe", 5) == 0 && s[11] == 0) adobe_rgb = true;
+        } else if (m == 0xDA) {
+            if (!have_frame || sl < 1) return JPG_BAD;
+            const int ns = s[0];
+            if (ns != f->ncomp) return JPG_UNSUPPORTED;              // one interleaved scan only
+            if (sl < (size_t)(1 + 2 * ns + 3)) return JPG_BAD;
+            for (int c = 0; c < ns; c++) {
+                if (s[1 + 2 * c] != f->c[c].id) return JPG_UNSUPPORTED;
+                f->c[c].td = s[2 + 2 * c] >> 4; f->c[c].ta = s[2 + 2 * c] & 15;
+                if (f->c[c].td > 3 || f->c[c].ta > 3) return JPG_BAD;
+                if (!f->dc[f->c[c].td].present || !f->ac[f->c[c].ta].present || !f->have_q[f->c[c].tq]) return JPG_BAD;
+            }
+            if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return JPG_BAD;
+            if (f->ncomp == 3) {
+                if (adobe_rgb) return JPG_UNSUPPORTED;
+                if (f->c[0].id == 'R' && f->c[1].id == 'G' && f->c[2].id == 'B') return JPG_UNSUPPORTED;
+                // luma at full resolution, both chroma planes alike: 4:4:4, 4:2:2 (h2v1) or 4:2:0 (h2v2)
+                const int h0 = f->c[0].h, v0 = f->c[0].v;
+                if (f->c[1].h != 1 || f->c[1].v != 1 || f->c[2].h != 1 || f->c[2].v != 1) return JPG_UNSUPPORTED;
+                if (!((h0 == 1 && v0 == 1) || (h0 == 2 && v0 == 1) || (h0 == 2 && v0 == 2))) return JPG_UNSUPPORTED;
+            } else if (f->c[0].h != 1 || f->c[0].v != 1) {
+                // a lone component is never interleaved: the sampling factors only scale the MCU, libjpeg resets them
+                f->c[0].h = f->c[0].v = 1;
+            }
+            f->hmax = f->vmax = 1;
+            for (int c = 0; c < f->ncomp; c++) { if (f->c[c].h > f->hmax) f->hmax = f->c[c].h; if (f->c[c].v > f->vmax) f->vmax = f->c[c].v; }
+            f->mcux = (f->X + 8 * f->hmax - 1) / (8 * f->hmax);
+            f->mcuy = (f->Y + 8 * f->vmax - 1) / (8 * f->vmax);
+            for (int c = 0; c < f->ncomp; c++) {
+                JpegComp& jc = f->c[c];
+                jc.bw = f->mcux * jc.h; jc.bh = f->mcuy * jc.v;
+                jc.dw = (f->X * jc.h + f->hmax - 1) / f->hmax; jc.dh = (f->Y * jc.v + f->vmax - 1) / f->vmax;
+                if (jc.dw < 2 && jc.h < f->hmax) return JPG_UNSUPPORTED;      // the fancy upsamplers need two columns
+            }
+            f->scan = d + p + L;
+            f->scan_len = n - (p + L);
+            return JPG_OK;
+        }
+        p += L;
+    }
+}
+
+struct JpegBits {
+    const uint8_t* d; size_t n, p = 0;
+    uint64_t acc = 0; int cnt = 0;
+    bool hit_marker = false;
+    long long real_bits = 0, used_bits = 0;      // bits delivered from the file / consumed since the last restart
+    JpegBits(const uint8_t* d_, size_t n_) : d(d_), n(n_) {}
+    inline void fill()
+    {
+        while (cnt <= 56) {
+            unsigned b = 0;
+            if (!hit_marker && p < n) {
+                b = d[p];
+                if (b == 0xFF) {
+                    const unsigned nx = p + 1 < n ? d[p + 1] : 0xD9;
+                    if (nx == 0) { p += 2; real_bits += 8; }
+                    else { hit_marker = true; b = 0; }                // feed zeros at a marker (as libjpeg does)
+                } else { p++; real_bits += 8; }
+            }
+            acc = (acc << 8) | b;
+            cnt += 8;
+        }
+    }
+    inline unsigned peek(int k) { if (cnt < k) fill(); return (unsigned)(acc >> (cnt - k)) & ((1u << k) - 1u); }
+    inline void skip(int k) { cnt -= k; used_bits += k; }
+    inline bool overrun() const { return used_bits > real_bits; }     // consumed padding zeros: the segment ended early
+    inline unsigned get(int k) { if (k == 0) return 0; const unsigned v = peek(k); skip(k); return v; }
+    // byte-align and step over the RSTn marker
+    inline bool restart()
+    {
+        if (overrun()) return false;
+        acc = 0; cnt = 0; real_bits = 0; used_bits = 0;
+        if (!hit_marker) {                                           // skip fill bytes up to the marker
+            while (p + 1 < n && !(d[p] == 0xFF && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7)) p++;
+        }
+        if (p + 1 >= n || d[p] != 0xFF || d[p + 1] < 0xD0 || d[p + 1] > 0xD7) return false;
+        p += 2;
+        hit_marker = false;
+        return true;
+    }
+};
+
+static inline int jpg_decode_sym(JpegBits& b, const JpegHuff& h)
+{
+    const unsigned look = b.peek(9);
+    const int l = h.look_len[look];
+    if (l) { b.skip(l); return h.look_sym[look]; }
+    int code = (int)b.get(9), len = 9;
+    while (len < 17 && code > h.maxcode[len]) { code = (code << 1) | (int)b.get(1); len++; }
+    if (len > 16) return -1;
+    return h.syms[(code + h.valoff[len]) & 255];
+}
+
+static inline int jpg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+// coef[c]: bh * bw blocks of 64 int16 in natural order, zero-initialised by the caller.
+static int jpg_decode_scan(const JpegFile& f, int16_t* const coef[3])
+{
+    JpegBits b(f.scan, f.scan_len);
+    int pred[3] = {0, 0, 0};
+    long long cnt = 0;
+    for (int my = 0; my < f.mcuy; my++)
+        for (int mx = 0; mx < f.mcux; mx++) {
+            if (f.dri && cnt && cnt % f.dri == 0) {
+                if (!b.restart()) return JPG_BAD;
+                pred[0] = pred[1] = pred[2] = 0;
+            }
+            cnt++;
+            for (int c = 0; c < f.ncomp; c++) {
+                const JpegComp& jc = f.c[c];
+                const JpegHuff& hd = f.dc[jc.td];
+                const JpegHuff& ha = f.ac[jc.ta];
+                for (int by = 0; by < jc.v; by++)
+                    for (int bx = 0; bx < jc.h; bx++) {
+                        int16_t* blk = coef[c] + ((size_t)(my * jc.v + by) * jc.bw + (size_t)(mx * jc.h + bx)) * 64;
+                        int s = jpg_decode_sym(b, hd);
+                        if (s < 0 || s > 11) return JPG_BAD;
+                        pred[c] += s ? jpg_extend((int)b.get(s), s) : 0;
+                        blk[0] = (int16_t)pred[c];
+                        for (int k = 1; k < 64;) {
+                            const int rs = jpg_decode_sym(b, ha);
+                            if (rs < 0) return JPG_BAD;
+                            const int r = rs >> 4;
+                            s = rs & 15;
+                            if (s) {
+                                k += r;
+                                if (k > 63) return JPG_BAD;
+                                blk[JPG_ZZ[k]] = (int16_t)jpg_extend((int)b.get(s), s);
+                                k++;
+                            } else if (r == 15) k += 16;
+                            else break;
+                        }
+                    }
+            }
+        }
+    return b.overrun() ? JPG_BAD : JPG_OK;
+}
+
+}  // namespace i2s

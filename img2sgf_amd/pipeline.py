@@ -123,6 +123,17 @@ def _detection_from_result(r: I2sResult) -> Detection:
         num_black_stones=r.n_black, num_white_stones=r.n_white, side_to_move=r.side_to_move)
 
 
+def jpeg_info(data: bytes, lib=None):
+    """(w, h, components) of a JPEG that i2s_detect_jpeg_batch can decode (sequential, 8-bit, Huffman, one interleaved scan);
+    raises I2sError for anything else (progressive, arithmetic, CMYK, not a JPEG).  Host-only: no GPU context needed."""
+    lib = lib if lib is not None else _lib.load()
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.dll.i2s_jpeg_info(data, len(data), C.byref(w), C.byref(h), C.byref(c))
+    if rc != 0:
+        raise I2sError(lib.dll.i2s_strerror(rc).decode())
+    return w.value, h.value, c.value
+
+
 class Detector:
     """One GPU context (one HIP stream on one device).  max_batch = images per device pass."""
 
@@ -195,6 +206,42 @@ class Detector:
         boards, res = self.detect_ptrs([im.ctypes.data for im in imgs], [im.shape[1] for im in imgs],
                                        [im.shape[0] for im in imgs], [im.strides[0] for im in imgs],
                                        [1 if im.ndim == 2 else 3 for im in imgs], params, False, full, xforms)
+        if not full:
+            return boards
+        return [_detection_from_result(r) for r in res]
+
+    def jpeg_info(self, data: bytes):
+        """(w, h, components) of a JPEG the device path can decode; raises I2sError (unsupported / invalid) otherwise."""
+        return jpeg_info(data, self.lib)
+
+    def detect_jpeg(self, blobs: Sequence[bytes], params: Optional[Params] = None, full=True, xforms=None):
+        """blobs: the bytes of baseline JPEG files.  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
+        (Huffman stage on the host), bit-exact with Pillow; then as detect_batch (xforms / Params.contrast / .brightness apply
+        to the decoded image).  Raises I2sError("parameter outside the supported envelope") for progressive and other
+        non-baseline files -- decode those with Pillow and call detect_batch."""
+        params = params or Params()
+        B = len(blobs)
+        arr = (C.c_char_p * B)(*blobs)
+        lens = (C.c_size_t * B)(*[len(b) for b in blobs])
+        boards = (I2sBoard * B)()
+        res = (I2sResult * B)() if full else None
+        xf = None
+        if xforms is not None:
+            xf = (I2sXform * B)()
+            for i, (aff, crop) in enumerate(xforms):
+                xf[i].affine[:] = [float(v) for v in aff]
+                xf[i].crop[:] = [int(v) for v in crop]
+            shapes = [(x.crop[3] - x.crop[1], x.crop[2] - x.crop[0]) for x in xf]
+        else:
+            shapes = [self.jpeg_info(b)[1::-1] for b in blobs]
+        p = params.to_c()
+        self._check(self.lib.dll.i2s_detect_jpeg_batch(self._ctx, B, arr, lens, xf, C.byref(p), boards, res))
+        n_last = (B - 1) % self.max_batch + 1 if B else 0
+        if params.schedule and B > self.max_batch:
+            order = sorted(range(B), key=lambda i: shapes[i][0] * shapes[i][1])
+            self._last_shapes = [shapes[i] for i in order[B - n_last:]]
+        else:
+            self._last_shapes = shapes[B - n_last:]
         if not full:
             return boards
         return [_detection_from_result(r) for r in res]
@@ -286,6 +333,42 @@ class StreamedDetector:
         self.dets = [Detector(device, max_batch, max_w, max_h, lib=lib) for _ in range(n_streams)]
         self.pool = ThreadPoolExecutor(max_workers=n_streams)
         self.max_batch = max_batch
+
+    def jpeg_info(self, data: bytes):
+        """(w, h, components) of a JPEG the device path can decode; raises I2sError (unsupported / invalid) otherwise."""
+        return jpeg_info(data, self.lib)
+
+    def detect_jpeg(self, blobs: Sequence[bytes], params: Optional[Params] = None, full=True, xforms=None):
+        """blobs: the bytes of baseline JPEG files.  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
+        (Huffman stage on the host), bit-exact with Pillow; then as detect_batch (xforms / Params.contrast / .brightness apply
+        to the decoded image).  Raises I2sError("parameter outside the supported envelope") for progressive and other
+        non-baseline files -- decode those with Pillow and call detect_batch."""
+        params = params or Params()
+        B = len(blobs)
+        arr = (C.c_char_p * B)(*blobs)
+        lens = (C.c_size_t * B)(*[len(b) for b in blobs])
+        boards = (I2sBoard * B)()
+        res = (I2sResult * B)() if full else None
+        xf = None
+        if xforms is not None:
+            xf = (I2sXform * B)()
+            for i, (aff, crop) in enumerate(xforms):
+                xf[i].affine[:] = [float(v) for v in aff]
+                xf[i].crop[:] = [int(v) for v in crop]
+            shapes = [(x.crop[3] - x.crop[1], x.crop[2] - x.crop[0]) for x in xf]
+        else:
+            shapes = [self.jpeg_info(b)[1::-1] for b in blobs]
+        p = params.to_c()
+        self._check(self.lib.dll.i2s_detect_jpeg_batch(self._ctx, B, arr, lens, xf, C.byref(p), boards, res))
+        n_last = (B - 1) % self.max_batch + 1 if B else 0
+        if params.schedule and B > self.max_batch:
+            order = sorted(range(B), key=lambda i: shapes[i][0] * shapes[i][1])
+            self._last_shapes = [shapes[i] for i in order[B - n_last:]]
+        else:
+            self._last_shapes = shapes[B - n_last:]
+        if not full:
+            return boards
+        return [_detection_from_result(r) for r in res]
 
     def detect_device(self, batch, params: Optional[Params] = None):
         n = len(self.dets)

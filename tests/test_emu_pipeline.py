@@ -195,3 +195,36 @@ def test_scheduled_ragged_batch_returns_input_order(lib):
         assert plain[k].sgf == sched[k].sgf and plain[k].status == sched[k].status, k
         np.testing.assert_array_equal(plain[k].circles_all, sched[k].circles_all)
     det.close()
+
+
+def test_jpeg_decode_matches_pillow(lib):
+    """SURVEY 8f-4 under the emulator: reference fixtures and Pillow-encoded images (4:4:4 / 4:2:2 / 4:2:0 / grey, restart
+    intervals) decoded by jpeg_host.h + k_jpeg.h must equal Image.open(...).convert("RGB"); progressive files are refused."""
+    import io
+    from PIL import Image
+    blobs = []
+    for n in ("no_circles.jpg", "ex9.jpg"):
+        with open(os.path.join(GOLDEN, "test_images", n), "rb") as f:
+            blobs.append(f.read())
+    rng = np.random.default_rng(31)
+    base = synth.synth_diagram(8, geom=synth.GEOM_SMALL)[0]
+    col = np.stack([base, np.roll(base, 5, 0), rng.integers(0, 256, base.shape, dtype=np.uint8)], -1)
+    for kw in (dict(subsampling=0, quality=90), dict(subsampling=1, quality=60, restart_marker_blocks=5),
+               dict(subsampling=2, quality=35, optimize=True, restart_marker_rows=1)):
+        buf = io.BytesIO()
+        Image.fromarray(col[:157, :203]).save(buf, "JPEG", **kw)
+        blobs.append(buf.getvalue())
+    buf = io.BytesIO()
+    Image.fromarray(base[:99, :131]).save(buf, "JPEG", quality=75)
+    blobs.append(buf.getvalue())
+    refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
+    det = Detector(0, len(blobs), 300, 260, lib=lib)
+    dets = det.detect_jpeg(blobs, Params(), full=True)
+    for k, (d, r) in enumerate(zip(dets, refs)):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d" % k)
+        parity.compare_detection(d, opipe.process_image(r))
+    with open(os.path.join(GOLDEN, "test_images", "ex3.jpg"), "rb") as f:
+        prog = f.read()
+    with pytest.raises(I2sError):
+        det.detect_jpeg([prog], Params(), full=False)
+    det.close()

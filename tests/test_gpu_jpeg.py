@@ -1,0 +1,136 @@
+"""JPEG decode on the device (Huffman stage on the host), pinned against Pillow itself.
+The reference enters through Image.open(path).convert("RGB") (img2sgf.py:651); i2s_detect_jpeg_batch must leave exactly those
+pixels in the staged source, for the reference's own baseline fixtures and for JPEGs Pillow encodes with every subsampling,
+quality, Huffman-table and restart-marker setting; non-baseline files must be refused, not approximated."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import parity
+from helpers import GOLDEN
+from img2sgf_amd import preprocess
+from img2sgf_amd.pipeline import Detector, I2sError, Params, board_to_sgf
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+
+IMAGES = ["ex%d.jpg" % i for i in range(1, 18)] + ["no_circles.jpg"]
+PROGRESSIVE = {"ex1.jpg", "ex3.jpg", "ex4.jpg", "ex5.jpg"}
+
+
+def _blob(name):
+    with open(os.path.join(GOLDEN, "test_images", name), "rb") as f:
+        return f.read()
+
+
+def test_baseline_fixtures_from_file_bytes():
+    """File bytes in, the whole reference flow on the device: decode, contrast 70 / brightness 50, detection."""
+    names = [n for n in IMAGES if n not in PROGRESSIVE]
+    blobs = [_blob(n) for n in names]
+    refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
+    det = Detector(0, len(names), max(r.shape[1] for r in refs), max(r.shape[0] for r in refs))
+    det.detect_jpeg(blobs, Params(), full=False)
+    for k, n in enumerate(names):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), refs[k], err_msg=n)
+    boards = det.detect_jpeg(blobs, Params(contrast=70, brightness=50), full=False)
+    for k, n in enumerate(names):
+        want = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n))
+        np.testing.assert_array_equal(det.fetch_source(k, 3), want, err_msg=n)
+        ref = opipe.process_image(want, keep_planes=False)
+        assert bool(boards[k].status == 0) == bool(ref.get("board_ready")), n
+        if ref.get("board_ready"):
+            assert board_to_sgf(boards[k]) == ref["sgf"], n
+    det.close()
+
+
+def test_non_baseline_files_are_refused():
+    det = Detector(0, 1, 800, 800)
+    for n in sorted(PROGRESSIVE):
+        with pytest.raises(I2sError):
+            det.jpeg_info(_blob(n))
+        with pytest.raises(I2sError):
+            det.detect_jpeg([_blob(n)], Params(), full=False)
+    with pytest.raises(I2sError):
+        det.detect_jpeg([b"\\xff\\xd8 not a jpeg"], Params(), full=False)
+    with pytest.raises(I2sError):
+        det.detect_jpeg([_blob("ex9.jpg")[:4000]], Params(), full=False)        # truncated entropy data
+    det.close()
+
+
+def _encode_random(rng):
+    h, w = int(rng.integers(3, 260)), int(rng.integers(3, 260))
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    elif kind == 1:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([(xx * 3 + yy) % 256, (yy * 2) % 256, (xx + yy * 5) % 256], -1).astype(np.uint8)
+    else:
+        src = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", "ex%d.jpg" % int(rng.integers(6, 18))))
+        img = np.ascontiguousarray(src[:h + 40, :w + 40])
+    pil = Image.fromarray(img)
+    if rng.random() < 0.3:
+        pil = pil.convert("L")
+    kw = dict(quality=int(rng.integers(5, 101)), optimize=bool(rng.random() < 0.5))
+    if pil.mode == "RGB":
+        kw["subsampling"] = int(rng.integers(0, 3))                  # 4:4:4, 4:2:2, 4:2:0
+    r = rng.random()
+    if r < 0.25:
+        kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+    elif r < 0.5:
+        kw["restart_marker_rows"] = int(rng.integers(1, 4))
+    buf = io.BytesIO()
+    pil.save(buf, "JPEG", **kw)
+    blob = buf.getvalue()
+    return blob, np.array(Image.open(io.BytesIO(blob)).convert("RGB"))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_pillow_encoded_images(seed):
+    """Random content and sizes, every encoder setting Pillow offers for sequential JPEGs (subsampling, quality, optimised
+    Huffman tables, restart intervals); every third seed adds the device rotate / crop on top."""
+    rng = np.random.default_rng(7000 + seed)
+    pairs = [_encode_random(rng) for _ in range(5)]
+    blobs, refs = [p[0] for p in pairs], [p[1] for p in pairs]
+    xfs, wants = None, refs
+    if seed % 3 == 0:
+        xfs, wants = [], []
+        for r in refs:
+            h, w = r.shape[:2]
+            ang = float(rng.uniform(-30, 30))
+            sel = (int(rng.integers(-3, 3)), int(rng.integers(-3, 3)), w - int(rng.integers(-3, 2)), h - int(rng.integers(-3, 2)))
+            xfs.append(preprocess.xform((w, h), ang, sel))
+            wants.append(np.array(Image.fromarray(r).rotate(angle=-ang, fillcolor="white", center=preprocess.rectangle_centre(sel)).crop(sel)))
+    det = Detector(0, 5, 310, 310)
+    dets = det.detect_jpeg(blobs, Params(), full=True, xforms=xfs)
+    for k, (d, want) in enumerate(zip(dets, wants)):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), want, err_msg="image %d" % k)
+        if d.status != 100:
+            parity.compare_detection(d, opipe.process_image(want))
+    det.close()
+
+
+def test_multi_pass_scheduled_jpeg_batch():
+    rng = np.random.default_rng(99)
+    blobs = [_encode_random(rng)[0] for _ in range(11)]
+    det = Detector(0, 11, 310, 310)
+    want = [bytes(b) for b in det.detect_jpeg(blobs, Params(), full=False)]
+    det.close()
+    det = Detector(0, 4, 310, 310)
+    for sched in (False, True):
+        got = det.detect_jpeg(blobs, Params(schedule=sched), full=False)
+        assert [bytes(b) for b in got] == want
+    det.close()
+
+
+def test_headless_cli_mixed_inputs(tmp_path):
+    """python -m img2sgf_amd with baseline JPEGs (decoded on the device) and a progressive one (opened with Pillow) in one call."""
+    from img2sgf_amd.__main__ import main
+    names = ["ex7.jpg", "ex1.jpg", "ex9.jpg", "ex13.jpg"]
+    assert main([os.path.join(GOLDEN, "test_images", n) for n in names] + ["-o", str(tmp_path)]) == 0
+    for n in names:
+        want = opipe.process_image(opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n)), keep_planes=False)
+        assert (tmp_path / n.replace(".jpg", ".sgf")).read_text() == want["sgf"], n
