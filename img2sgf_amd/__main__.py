@@ -31,8 +31,8 @@ def main(argv=None):
     import numpy as np
     params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
                              contrast=args.contrast, brightness=args.brightness, schedule=True)
-    # Sequential JPEGs are decoded on the GPU straight from the file bytes (bit-exact with Pillow's decoder); anything else
-    # (progressive JPEG, PNG, ...) is opened with Pillow as the reference does (img2sgf.py:651).  Rotate / crop / contrast /
+    # Huffman-coded JPEGs (sequential or progressive) are decoded on the GPU straight from the file bytes (bit-exact with
+    # Pillow's decoder); anything else (PNG, CMYK JPEG, ...) is opened with Pillow as the reference does (img2sgf.py:651).  Rotate / crop / contrast /
     # brightness run on the GPU either way.
     blobs, sizes = {}, []
     for k, path in enumerate(inputs):

@@ -668,7 +668,7 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
                 J.bw[c] = f.c[c].bw; J.bh[c] = f.c[c].bh; J.dw[c] = f.c[c].dw; J.dh[c] = f.c[c].dh;
                 J.nblocks[c] = (int)nblk;
                 blocks += (int)nblk;
-                for (int q = 0; q < 64; q++) J.q[c][q] = f.q[f.c[c].tq][q];
+                for (int q = 0; q < 64; q++) J.q[c][q] = f.qc[c][q];
             }
             J.ncomp = f.ncomp; J.X = f.X; J.Y = f.Y; J.hs = f.c[0].h; J.vs = f.c[0].v;
             J.out = ctx->d_jpg + ro; J.out_stride = f.X * 3;

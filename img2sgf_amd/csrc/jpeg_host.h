@@ -2,13 +2,17 @@
 // scan -- into quantised DCT coefficient blocks.  Everything after that (dequantisation, inverse DCT, chroma upsampling,
 // colour conversion: csrc/k_jpeg.h) runs on the device.  The reference reaches the same pixels through
 // PIL.Image.open(path).convert("RGB") (img2sgf.py:651), i.e. libjpeg-turbo with its defaults (JDCT_ISLOW, fancy upsampling);
-// this file and k_jpeg.h restate exactly that decoder for sequential 8-bit Huffman JPEGs (SOF0 / SOF1, one interleaved scan,
-// 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0).  Everything else (progressive, arithmetic coding, multi-scan, CMYK, RGB-coded,
-// 12-bit) is reported as unsupported so that the caller can decode it elsewhere; nothing is approximated.
+// this file and k_jpeg.h restate exactly that decoder for 8-bit Huffman JPEGs, sequential (SOF0 / SOF1) and progressive (SOF2,
+// spectral selection + successive approximation; a complete file needs no block smoothing, so the pixels are the inverse DCT
+// of the final coefficients), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, any scan script.  Everything else (arithmetic coding,
+// lossless, CMYK, RGB-coded, 12-bit) is reported as unsupported so that the caller can decode it elsewhere; nothing is
+// approximated.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+
+#include <vector>
 
 namespace i2s {
 
@@ -27,14 +31,22 @@ struct JpegHuff {
     uint8_t syms[256];
 };
 
+struct JpegScan {
+    int ns = 0, ci[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int ss = 0, se = 63, ah = 0, al = 0, dri = 0;
+    JpegHuff dc[4], ac[4];     // the tables in force at this SOS (they may be redefined between scans)
+    const uint8_t* data = nullptr;
+    size_t len = 0;
+};
+
 struct JpegFile {
-    int X = 0, Y = 0, ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, dri = 0;
+    int X = 0, Y = 0, ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
+    bool progressive = false;
     JpegComp c[3];
-    uint16_t q[4][64];         // natural (row-major) order
+    uint16_t q[4][64];         // natural (row-major) order, as in force when the FIRST scan of a component starts (libjpeg latches them there)
+    uint16_t qc[3][64];        // per component
     bool have_q[4] = {false, false, false, false};
-    JpegHuff dc[4], ac[4];
-    const uint8_t* scan = nullptr;
-    size_t scan_len = 0;
+    std::vector<JpegScan> scans;
 };
 
 enum { JPG_OK = 0, JPG_BAD = 1, JPG_UNSUPPORTED = 2 };
@@ -66,18 +78,20 @@ static int jpg_build_huff(const uint8_t* counts, const uint8_t* syms, int nsyms,
     return JPG_OK;
 }
 
-// Parses the markers up to and including the (single) start of scan.
+// Parses the whole file: frame header, tables, and every scan (with the entropy-coded segment that follows it).
 static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
 {
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return JPG_BAD;
     size_t p = 2;
-    bool have_frame = false, adobe_rgb = false;
+    bool have_frame = false, adobe_rgb = false, latched[3] = {false, false, false};
+    JpegHuff dc[4], ac[4];
+    int dri = 0;
     for (;;) {
-        if (p + 4 > n || d[p] != 0xFF) return JPG_BAD;
+        if (p + 2 > n || d[p] != 0xFF) return f->scans.empty() ? JPG_BAD : JPG_OK;       // data ends without EOI: use what is there
         while (p + 1 < n && d[p + 1] == 0xFF) p++;
         const int m = d[p + 1];
         p += 2;
-        if (m == 0xD9) return JPG_BAD;                               // EOI before any scan
+        if (m == 0xD9) break;
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;         // parameterless markers
         if (p + 2 > n) return JPG_BAD;
         const size_t L = ((size_t)d[p] << 8) | d[p + 1];
@@ -96,9 +110,10 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
                 f->have_q[tq] = true;
                 i += 64;
             }
-        } else if (m == 0xC0 || m == 0xC1) {
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             if (sl < 6 || have_frame) return JPG_BAD;
             if (s[0] != 8) return JPG_UNSUPPORTED;
+            f->progressive = m == 0xC2;
             f->Y = (s[1] << 8) | s[2]; f->X = (s[3] << 8) | s[4]; f->ncomp = s[5];
             if (f->X < 1 || f->Y < 1) return JPG_UNSUPPORTED;        // Y == 0 (DNL) is not handled
             if (f->ncomp != 1 && f->ncomp != 3) return JPG_UNSUPPORTED;
@@ -108,51 +123,14 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
                 jc.id = s[6 + 3 * c]; jc.h = s[7 + 3 * c] >> 4; jc.v = s[7 + 3 * c] & 15; jc.tq = s[8 + 3 * c];
                 if (jc.h < 1 || jc.v < 1 || jc.h > 4 || jc.v > 4 || jc.tq > 3) return JPG_BAD;
             }
-            have_frame = true;
-        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            return JPG_UNSUPPORTED;                                  // progressive, lossless, hierarchical, arithmetic
-        } else if (m == 0xCC) {
-            return JPG_UNSUPPORTED;
-        } else if (m == 0xC4) {
-            size_t i = 0;
-            while (i < sl) {
-                const int tc = s[i] >> 4, th = s[i] & 15;
-                i++;
-                if (tc > 1 || th > 3 || i + 16 > sl) return JPG_BAD;
-                int cnt = 0;
-                for (int k = 0; k < 16; k++) cnt += s[i + k];
-                if (cnt > 256 || i + 16 + (size_t)cnt > sl) return JPG_BAD;
-                if (jpg_build_huff(s + i, s + i + 16, cnt, tc ? &f->ac[th] : &f->dc[th])) return JPG_BAD;
-                i += 16 + (size_t)cnt;
-            }
-        } else if (m == 0xDD) {
-            if (sl < 2) return JPG_BAD;
-            f->dri = (s[0] << 8) | s[1];
-        } else if (m == 0xEE) {
-            // Adobe marker: transform 0 with three components means the data are RGB, not YCbCr
-            if (sl >= 12 && memcmp(s, "Adobe", 5) == 0 && s[11] == 0) adobe_rgb = true;
-        } else if (m == 0xDA) {
-            if (!have_frame || sl < 1) return JPG_BAD;
-            const int ns = s[0];
-            if (ns != f->ncomp) return JPG_UNSUPPORTED;              // one interleaved scan only
-            if (sl < (size_t)(1 + 2 * ns + 3)) return JPG_BAD;
-            for (int c = 0; c < ns; c++) {
-                if (s[1 + 2 * c] != f->c[c].id) return JPG_UNSUPPORTED;
-                f->c[c].td = s[2 + 2 * c] >> 4; f->c[c].ta = s[2 + 2 * c] & 15;
-                if (f->c[c].td > 3 || f->c[c].ta > 3) return JPG_BAD;
-                if (!f->dc[f->c[c].td].present || !f->ac[f->c[c].ta].present || !f->have_q[f->c[c].tq]) return JPG_BAD;
-            }
-            if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return JPG_BAD;
             if (f->ncomp == 3) {
-                if (adobe_rgb) return JPG_UNSUPPORTED;
-                if (f->c[0].id == 'R' && f->c[1].id == 'G' && f->c[2].id == 'B') return JPG_UNSUPPORTED;
                 // luma at full resolution, both chroma planes alike: 4:4:4, 4:2:2 (h2v1) or 4:2:0 (h2v2)
                 const int h0 = f->c[0].h, v0 = f->c[0].v;
                 if (f->c[1].h != 1 || f->c[1].v != 1 || f->c[2].h != 1 || f->c[2].v != 1) return JPG_UNSUPPORTED;
                 if (!((h0 == 1 && v0 == 1) || (h0 == 2 && v0 == 1) || (h0 == 2 && v0 == 2))) return JPG_UNSUPPORTED;
-            } else if (f->c[0].h != 1 || f->c[0].v != 1) {
-                // a lone component is never interleaved: the sampling factors only scale the MCU, libjpeg resets them
-                f->c[0].h = f->c[0].v = 1;
+                if (f->c[0].id == 'R' && f->c[1].id == 'G' && f->c[2].id == 'B') return JPG_UNSUPPORTED;
+            } else {
+                f->c[0].h = f->c[0].v = 1;     // a lone component: the sampling factors only scale the MCU, libjpeg ignores them
             }
             f->hmax = f->vmax = 1;
             for (int c = 0; c < f->ncomp; c++) { if (f->c[c].h > f->hmax) f->hmax = f->c[c].h; if (f->c[c].v > f->vmax) f->vmax = f->c[c].v; }
@@ -162,14 +140,77 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
                 JpegComp& jc = f->c[c];
                 jc.bw = f->mcux * jc.h; jc.bh = f->mcuy * jc.v;
                 jc.dw = (f->X * jc.h + f->hmax - 1) / f->hmax; jc.dh = (f->Y * jc.v + f->vmax - 1) / f->vmax;
-                if (jc.dw < 2 && jc.h < f->hmax) return JPG_UNSUPPORTED;      // the fancy upsamplers need two columns
             }
-            f->scan = d + p + L;
-            f->scan_len = n - (p + L);
-            return JPG_OK;
+            have_frame = true;
+        } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8) {
+            return JPG_UNSUPPORTED;                                  // lossless, hierarchical, arithmetic coding
+        } else if (m == 0xC4) {
+            size_t i = 0;
+            while (i < sl) {
+                const int tc = s[i] >> 4, th = s[i] & 15;
+                i++;
+                if (tc > 1 || th > 3 || i + 16 > sl) return JPG_BAD;
+                int cnt = 0;
+                for (int k = 0; k < 16; k++) cnt += s[i + k];
+                if (cnt > 256 || i + 16 + (size_t)cnt > sl) return JPG_BAD;
+                if (jpg_build_huff(s + i, s + i + 16, cnt, tc ? &ac[th] : &dc[th])) return JPG_BAD;
+                i += 16 + (size_t)cnt;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) return JPG_BAD;
+            dri = (s[0] << 8) | s[1];
+        } else if (m == 0xEE) {
+            // Adobe marker: transform 0 with three components means the data are RGB, not YCbCr
+            if (sl >= 12 && memcmp(s, "Adobe", 5) == 0 && s[11] == 0) adobe_rgb = true;
+        } else if (m == 0xDA) {
+            if (!have_frame || sl < 1) return JPG_BAD;
+            if (adobe_rgb && f->ncomp == 3) return JPG_UNSUPPORTED;
+            JpegScan sc;
+            sc.ns = s[0];
+            if (sc.ns < 1 || sc.ns > f->ncomp || sl < (size_t)(1 + 2 * sc.ns + 3)) return JPG_BAD;
+            for (int k = 0; k < sc.ns; k++) {
+                int ci = -1;
+                for (int c = 0; c < f->ncomp; c++) if (f->c[c].id == s[1 + 2 * k]) ci = c;
+                if (ci < 0 || (k > 0 && ci <= sc.ci[k - 1])) return JPG_BAD;
+                sc.ci[k] = ci; sc.td[k] = s[2 + 2 * k] >> 4; sc.ta[k] = s[2 + 2 * k] & 15;
+                if (sc.td[k] > 3 || sc.ta[k] > 3) return JPG_BAD;
+                if (!latched[ci]) {                                  // libjpeg's latch_quant_tables
+                    if (!f->have_q[f->c[ci].tq]) return JPG_BAD;
+                    memcpy(f->qc[ci], f->q[f->c[ci].tq], sizeof(f->qc[ci]));
+                    latched[ci] = true;
+                }
+            }
+            sc.ss = s[1 + 2 * sc.ns]; sc.se = s[2 + 2 * sc.ns]; sc.ah = s[3 + 2 * sc.ns] >> 4; sc.al = s[3 + 2 * sc.ns] & 15;
+            if (f->progressive) {
+                if (sc.ss > sc.se || sc.se > 63 || sc.al > 13 || sc.ah > 13) return JPG_BAD;
+                if (sc.ss == 0 ? sc.se != 0 : sc.ns != 1) return JPG_BAD;      // DC scans hold DC only; AC scans one component
+                if (sc.ah != 0 && sc.ah != sc.al + 1) return JPG_BAD;
+            } else if (sc.ss != 0 || sc.se != 63 || sc.ah != 0 || sc.al != 0) return JPG_BAD;
+            for (int k = 0; k < sc.ns; k++) {
+                const bool need_dc = sc.ss == 0 && sc.ah == 0, need_ac = sc.se > 0;
+                if ((need_dc && !dc[sc.td[k]].present) || (need_ac && !ac[sc.ta[k]].present)) return JPG_BAD;
+            }
+            for (int t = 0; t < 4; t++) { sc.dc[t] = dc[t]; sc.ac[t] = ac[t]; }
+            sc.dri = dri;
+            // the entropy-coded segment runs up to the next marker that is neither a stuffed FF00 nor RSTn
+            size_t q0 = p + L, q = q0;
+            while (q < n) {
+                if (d[q] == 0xFF && q + 1 < n && d[q + 1] != 0 && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7)) {
+                    if (d[q + 1] == 0xFF) { q++; continue; }         // fill byte
+                    break;
+                }
+                q++;
+            }
+            sc.data = d + q0; sc.len = q - q0;
+            f->scans.push_back(sc);
+            p = q;
+            continue;
         }
         p += L;
     }
+    if (!have_frame || f->scans.empty()) return JPG_BAD;
+    for (int c = 0; c < f->ncomp; c++) if (!latched[c]) return JPG_BAD;          // a component that no scan mentions
+    return JPG_OK;
 }
 
 struct JpegBits {
@@ -226,47 +267,140 @@ static inline int jpg_decode_sym(JpegBits& b, const JpegHuff& h)
 
 static inline int jpg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
-// coef[c]: bh * bw blocks of 64 int16 in natural order, zero-initialised by the caller.
-static int jpg_decode_scan(const JpegFile& f, int16_t* const coef[3])
+// One block of a sequential scan.
+static inline int jpg_block_sequential(JpegBits& b, const JpegHuff& hd, const JpegHuff& ha, int& pred, int16_t* blk)
 {
-    JpegBits b(f.scan, f.scan_len);
-    int pred[3] = {0, 0, 0};
-    long long cnt = 0;
-    for (int my = 0; my < f.mcuy; my++)
-        for (int mx = 0; mx < f.mcux; mx++) {
-            if (f.dri && cnt && cnt % f.dri == 0) {
-                if (!b.restart()) return JPG_BAD;
-                pred[0] = pred[1] = pred[2] = 0;
+    int s = jpg_decode_sym(b, hd);
+    if (s < 0 || s > 11) return JPG_BAD;
+    pred += s ? jpg_extend((int)b.get(s), s) : 0;
+    blk[0] = (int16_t)pred;
+    for (int k = 1; k < 64;) {
+        const int rs = jpg_decode_sym(b, ha);
+        if (rs < 0) return JPG_BAD;
+        const int r = rs >> 4;
+        s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > 63) return JPG_BAD;
+            blk[JPG_ZZ[k]] = (int16_t)jpg_extend((int)b.get(s), s);
+            k++;
+        } else if (r == 15) k += 16;
+        else break;
+    }
+    return JPG_OK;
+}
+
+// Progressive AC, first pass of a band (jdphuff.c decode_mcu_AC_first).
+static inline int jpg_block_ac_first(JpegBits& b, const JpegHuff& ha, int ss, int se, int al, unsigned& eobrun, int16_t* blk)
+{
+    if (eobrun > 0) { eobrun--; return JPG_OK; }
+    for (int k = ss; k <= se; k++) {
+        const int rs = jpg_decode_sym(b, ha);
+        if (rs < 0) return JPG_BAD;
+        const int r = rs >> 4, s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > 63) return JPG_BAD;
+            blk[JPG_ZZ[k]] = (int16_t)(jpg_extend((int)b.get(s), s) * (1 << al));
+        } else if (r == 15) k += 15;
+        else {
+            eobrun = 1u << r;
+            if (r) eobrun += b.get(r);
+            eobrun--;                                               // this block is the first of the run
+            break;
+        }
+    }
+    return JPG_OK;
+}
+
+// Progressive AC, refinement pass (jdphuff.c decode_mcu_AC_refine): one more bit for the coefficients that are already
+// non-zero, and newly non-zero coefficients (+-1 << al) placed after skipping r zero-valued positions.
+static inline int jpg_block_ac_refine(JpegBits& b, const JpegHuff& ha, int ss, int se, int al, unsigned& eobrun, int16_t* blk)
+{
+    const int p1 = 1 << al, m1 = -(1 << al);
+    int k = ss;
+    if (eobrun == 0) {
+        for (; k <= se; k++) {
+            const int rs = jpg_decode_sym(b, ha);
+            if (rs < 0) return JPG_BAD;
+            int r = rs >> 4, s = rs & 15;
+            if (s) {
+                if (s != 1) return JPG_BAD;
+                s = b.get(1) ? p1 : m1;
+            } else if (r != 15) {
+                eobrun = 1u << r;
+                if (r) eobrun += b.get(r);
+                break;                                              // the rest of this block is handled as part of the run
             }
-            cnt++;
-            for (int c = 0; c < f.ncomp; c++) {
-                const JpegComp& jc = f.c[c];
-                const JpegHuff& hd = f.dc[jc.td];
-                const JpegHuff& ha = f.ac[jc.ta];
-                for (int by = 0; by < jc.v; by++)
-                    for (int bx = 0; bx < jc.h; bx++) {
-                        int16_t* blk = coef[c] + ((size_t)(my * jc.v + by) * jc.bw + (size_t)(mx * jc.h + bx)) * 64;
-                        int s = jpg_decode_sym(b, hd);
-                        if (s < 0 || s > 11) return JPG_BAD;
-                        pred[c] += s ? jpg_extend((int)b.get(s), s) : 0;
-                        blk[0] = (int16_t)pred[c];
-                        for (int k = 1; k < 64;) {
-                            const int rs = jpg_decode_sym(b, ha);
-                            if (rs < 0) return JPG_BAD;
-                            const int r = rs >> 4;
-                            s = rs & 15;
-                            if (s) {
-                                k += r;
-                                if (k > 63) return JPG_BAD;
-                                blk[JPG_ZZ[k]] = (int16_t)jpg_extend((int)b.get(s), s);
-                                k++;
-                            } else if (r == 15) k += 16;
-                            else break;
-                        }
-                    }
+            // advance over already-non-zero coefficients (each takes a correction bit) and r zero ones
+            do {
+                int16_t* c = blk + JPG_ZZ[k];
+                if (*c != 0) {
+                    if (b.get(1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                } else if (--r < 0) break;
+                k++;
+            } while (k <= se);
+            if (s) {
+                if (k > 63) return JPG_BAD;
+                blk[JPG_ZZ[k]] = (int16_t)s;
             }
         }
-    return b.overrun() ? JPG_BAD : JPG_OK;
+    }
+    if (eobrun > 0) {
+        for (; k <= se; k++) {
+            int16_t* c = blk + JPG_ZZ[k];
+            if (*c != 0 && b.get(1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+        }
+        eobrun--;
+    }
+    return JPG_OK;
+}
+
+// coef[c]: bh * bw blocks of 64 int16 in natural order, zero-initialised by the caller; all scans are applied in file order.
+static int jpg_decode_scan(const JpegFile& f, int16_t* const coef[3])
+{
+    for (const JpegScan& sc : f.scans) {
+        JpegBits b(sc.data, sc.len);
+        int pred[3] = {0, 0, 0};
+        unsigned eobrun = 0;
+        long long cnt = 0;
+        // a scan of one component is not interleaved: its MCU is one block and it covers only the blocks that hold image samples
+        const bool single = sc.ns == 1;
+        const JpegComp& c0 = f.c[sc.ci[0]];
+        const int nx = single ? (c0.dw + 7) / 8 : f.mcux, ny = single ? (c0.dh + 7) / 8 : f.mcuy;
+        for (int my = 0; my < ny; my++)
+            for (int mx = 0; mx < nx; mx++) {
+                if (sc.dri && cnt && cnt % sc.dri == 0) {
+                    if (!b.restart()) return JPG_BAD;
+                    pred[0] = pred[1] = pred[2] = 0;
+                    eobrun = 0;
+                }
+                cnt++;
+                for (int k = 0; k < sc.ns; k++) {
+                    const JpegComp& jc = f.c[sc.ci[k]];
+                    const int nbx = single ? 1 : jc.h, nby = single ? 1 : jc.v;
+                    for (int by = 0; by < nby; by++)
+                        for (int bx = 0; bx < nbx; bx++) {
+                            const int row = single ? my : my * jc.v + by, col = single ? mx : mx * jc.h + bx;
+                            int16_t* blk = coef[sc.ci[k]] + ((size_t)row * jc.bw + (size_t)col) * 64;
+                            int rc = JPG_OK;
+                            if (!f.progressive) rc = jpg_block_sequential(b, sc.dc[sc.td[k]], sc.ac[sc.ta[k]], pred[k], blk);
+                            else if (sc.ss == 0) {
+                                if (sc.ah == 0) {                    // DC first pass: the difference, scaled
+                                    const int s = jpg_decode_sym(b, sc.dc[sc.td[k]]);
+                                    if (s < 0 || s > 11) return JPG_BAD;
+                                    pred[k] += s ? jpg_extend((int)b.get(s), s) : 0;
+                                    blk[0] = (int16_t)(pred[k] * (1 << sc.al));
+                                } else if (b.get(1)) blk[0] = (int16_t)(blk[0] | (1 << sc.al));      // DC refinement: one bit
+                            } else if (sc.ah == 0) rc = jpg_block_ac_first(b, sc.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
+                            else rc = jpg_block_ac_refine(b, sc.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
+                            if (rc) return rc;
+                        }
+                }
+            }
+        if (b.overrun()) return JPG_BAD;
+    }
+    return JPG_OK;
 }
 
 }  // namespace i2s

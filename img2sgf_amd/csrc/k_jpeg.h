@@ -1,4 +1,4 @@
-// Device half of the baseline JPEG decoder (host half: jpeg_host.h): dequantisation + inverse DCT of every
+// Device half of the JPEG decoder (host half: jpeg_host.h): dequantisation + inverse DCT of every
 // 8x8 block, then chroma upsampling + colour conversion straight into an interleaved RGB image -- the pixels
 // PIL.Image.open(path).convert("RGB") (img2sgf.py:651) yields, bit for bit.  Restated from libjpeg(-turbo), which Pillow
 // runs with its defaults:
@@ -90,6 +90,8 @@ __device__ __forceinline__ int jpg_chroma(const uint8_t* __restrict__ p, int pit
 {
     if (hs == 1) return p[(size_t)y * pitch + x];
     const int c = x >> 1;
+    // libjpeg only installs the fancy upsamplers for components more than 2 samples wide; narrower ones are replicated
+    if (dw <= 2) return p[(size_t)(vs == 2 ? y >> 1 : y) * pitch + c];
     if (vs == 1) {
         // h2v1 fancy: 3/4 this + 1/4 neighbour, rounding 1 (left half) / 2 (right half); the outermost samples are copied
         const uint8_t* r = p + (size_t)y * pitch;

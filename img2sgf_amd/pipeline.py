@@ -124,8 +124,8 @@ def _detection_from_result(r: I2sResult) -> Detection:
 
 
 def jpeg_info(data: bytes, lib=None):
-    """(w, h, components) of a JPEG that i2s_detect_jpeg_batch can decode (sequential, 8-bit, Huffman, one interleaved scan);
-    raises I2sError for anything else (progressive, arithmetic, CMYK, not a JPEG).  Host-only: no GPU context needed."""
+    """(w, h, components) of a JPEG that i2s_detect_jpeg_batch can decode (8-bit, Huffman-coded, sequential or progressive, grey or YCbCr);
+    raises I2sError for anything else (arithmetic, CMYK, not a JPEG).  Host-only: no GPU context needed."""
     lib = lib if lib is not None else _lib.load()
     w, h, c = C.c_int(), C.c_int(), C.c_int()
     rc = lib.dll.i2s_jpeg_info(data, len(data), C.byref(w), C.byref(h), C.byref(c))
@@ -215,10 +215,10 @@ class Detector:
         return jpeg_info(data, self.lib)
 
     def detect_jpeg(self, blobs: Sequence[bytes], params: Optional[Params] = None, full=True, xforms=None):
-        """blobs: the bytes of baseline JPEG files.  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
+        """blobs: the bytes of JPEG files (8-bit, Huffman-coded, sequential or progressive).  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
         (Huffman stage on the host), bit-exact with Pillow; then as detect_batch (xforms / Params.contrast / .brightness apply
-        to the decoded image).  Raises I2sError("parameter outside the supported envelope") for progressive and other
-        non-baseline files -- decode those with Pillow and call detect_batch."""
+        to the decoded image).  Raises I2sError("parameter outside the supported envelope") for CMYK, arithmetic-coded
+        and other flavours -- decode those with Pillow and call detect_batch."""
         params = params or Params()
         B = len(blobs)
         arr = (C.c_char_p * B)(*blobs)
@@ -339,10 +339,10 @@ class StreamedDetector:
         return jpeg_info(data, self.lib)
 
     def detect_jpeg(self, blobs: Sequence[bytes], params: Optional[Params] = None, full=True, xforms=None):
-        """blobs: the bytes of baseline JPEG files.  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
+        """blobs: the bytes of JPEG files (8-bit, Huffman-coded, sequential or progressive).  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
         (Huffman stage on the host), bit-exact with Pillow; then as detect_batch (xforms / Params.contrast / .brightness apply
-        to the decoded image).  Raises I2sError("parameter outside the supported envelope") for progressive and other
-        non-baseline files -- decode those with Pillow and call detect_batch."""
+        to the decoded image).  Raises I2sError("parameter outside the supported envelope") for CMYK, arithmetic-coded
+        and other flavours -- decode those with Pillow and call detect_batch."""
         params = params or Params()
         B = len(blobs)
         arr = (C.c_char_p * B)(*blobs)

@@ -18,7 +18,7 @@
  *   i2s_choose_threshold  choose_threshold() 606-613.
  *   i2s_detect_batch_xf   the same, preceded on the device by crop_and_rotate_image() 110-114
  *                         (PIL Image.rotate(NEAREST, fillcolor white, center) + Image.crop).
- *   i2s_detect_jpeg_batch the same from JPEG bytes: Image.open(...).convert("RGB") 651 for baseline JPEGs, decoded on
+ *   i2s_detect_jpeg_batch the same from JPEG bytes: Image.open(...).convert("RGB") 651 for Huffman JPEGs, decoded on
  *                         the device (Huffman stage on the host).
  *   i2s_fetch_source      input_image_np 150 after the on-device rotate / crop (110-114) and contrast / brightness
  *                         (141-149) steps, if enabled.
@@ -198,11 +198,11 @@ int  i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* img,
                          const int* w, const int* h, const int* stride, const int* channels,
                          const i2s_xform* xf, const i2s_params* p, i2s_board* boards, i2s_result* full);
 
-/* JPEG input: Image.open(path).convert("RGB") (img2sgf.py:651) for sequential 8-bit Huffman JPEGs (one
- * interleaved scan, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0), bit-exact with Pillow / libjpeg-turbo: entropy decoding on the
- * host, dequantisation + inverse DCT + chroma upsampling + colour conversion on the device, then the ordinary path (xf and the
- * contrast / brightness step of p apply to the decoded image).  I2S_E_UNSUPPORTED for any other JPEG flavour (progressive,
- * arithmetic, multi-scan, CMYK ...): nothing is approximated, decode those elsewhere and use i2s_detect_batch(_xf).
+/* JPEG input: Image.open(path).convert("RGB") (img2sgf.py:651) for 8-bit Huffman JPEGs, sequential or
+ * progressive (grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, any scan script), bit-exact with Pillow / libjpeg-turbo: entropy decoding
+ * on the host, dequantisation + inverse DCT + chroma upsampling + colour conversion on the device, then the ordinary path (xf
+ * and the contrast / brightness step of p apply to the decoded image).  I2S_E_UNSUPPORTED for any other flavour (arithmetic
+ * coding, CMYK, RGB-coded, 12-bit, lossless): nothing is approximated, decode those elsewhere and use i2s_detect_batch(_xf).
  * i2s_jpeg_info reports the frame size (and 1 or 3 components) or the same error codes without decoding. */
 int  i2s_jpeg_info(const uint8_t* data, size_t len, int* w, int* h, int* channels);
 int  i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* jpeg, const size_t* len,

@@ -199,7 +199,7 @@ def test_scheduled_ragged_batch_returns_input_order(lib):
 
 def test_jpeg_decode_matches_pillow(lib):
     """SURVEY 8f-4 under the emulator: reference fixtures and Pillow-encoded images (4:4:4 / 4:2:2 / 4:2:0 / grey, restart
-    intervals) decoded by jpeg_host.h + k_jpeg.h must equal Image.open(...).convert("RGB"); progressive files are refused."""
+    intervals, progressive) decoded by jpeg_host.h + k_jpeg.h must equal Image.open(...).convert("RGB"); CMYK is refused."""
     import io
     from PIL import Image
     blobs = []
@@ -210,7 +210,8 @@ def test_jpeg_decode_matches_pillow(lib):
     base = synth.synth_diagram(8, geom=synth.GEOM_SMALL)[0]
     col = np.stack([base, np.roll(base, 5, 0), rng.integers(0, 256, base.shape, dtype=np.uint8)], -1)
     for kw in (dict(subsampling=0, quality=90), dict(subsampling=1, quality=60, restart_marker_blocks=5),
-               dict(subsampling=2, quality=35, optimize=True, restart_marker_rows=1)):
+               dict(subsampling=2, quality=35, optimize=True, restart_marker_rows=1),
+               dict(subsampling=2, quality=50, progressive=True), dict(subsampling=0, quality=20, progressive=True, restart_marker_blocks=7)):
         buf = io.BytesIO()
         Image.fromarray(col[:157, :203]).save(buf, "JPEG", **kw)
         blobs.append(buf.getvalue())
@@ -223,8 +224,8 @@ def test_jpeg_decode_matches_pillow(lib):
     for k, (d, r) in enumerate(zip(dets, refs)):
         np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d" % k)
         parity.compare_detection(d, opipe.process_image(r))
-    with open(os.path.join(GOLDEN, "test_images", "ex3.jpg"), "rb") as f:
-        prog = f.read()
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((24, 24, 4), np.uint8), "CMYK").save(buf, "JPEG")
     with pytest.raises(I2sError):
-        det.detect_jpeg([prog], Params(), full=False)
+        det.detect_jpeg([buf.getvalue()], Params(), full=False)
     det.close()

@@ -1,7 +1,8 @@
 """JPEG decode on the device (Huffman stage on the host), pinned against Pillow itself.
 The reference enters through Image.open(path).convert("RGB") (img2sgf.py:651); i2s_detect_jpeg_batch must leave exactly those
-pixels in the staged source, for the reference's own baseline fixtures and for JPEGs Pillow encodes with every subsampling,
-quality, Huffman-table and restart-marker setting; non-baseline files must be refused, not approximated."""
+pixels in the staged source, for the reference's own fixtures (14 sequential, 4 progressive) and for JPEGs Pillow encodes with
+every subsampling, quality, Huffman-table, restart-marker and progressive setting; other flavours (CMYK ...) must be refused,
+not approximated."""
 import io
 import os
 
@@ -18,7 +19,6 @@ from oracle import pipeline as opipe
 pytestmark = pytest.mark.gpu
 
 IMAGES = ["ex%d.jpg" % i for i in range(1, 18)] + ["no_circles.jpg"]
-PROGRESSIVE = {"ex1.jpg", "ex3.jpg", "ex4.jpg", "ex5.jpg"}
 
 
 def _blob(name):
@@ -26,9 +26,9 @@ def _blob(name):
         return f.read()
 
 
-def test_baseline_fixtures_from_file_bytes():
+def test_all_fixtures_from_file_bytes():
     """File bytes in, the whole reference flow on the device: decode, contrast 70 / brightness 50, detection."""
-    names = [n for n in IMAGES if n not in PROGRESSIVE]
+    names = list(IMAGES)
     blobs = [_blob(n) for n in names]
     refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
     det = Detector(0, len(names), max(r.shape[1] for r in refs), max(r.shape[0] for r in refs))
@@ -46,22 +46,21 @@ def test_baseline_fixtures_from_file_bytes():
     det.close()
 
 
-def test_non_baseline_files_are_refused():
+def test_unsupported_or_broken_files_are_refused():
     det = Detector(0, 1, 800, 800)
-    for n in sorted(PROGRESSIVE):
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((40, 40, 4), np.uint8), "CMYK").save(buf, "JPEG")
+    for blob in (buf.getvalue(), b"\xff\xd8 not a jpeg", _blob("ex9.jpg")[:4000], _blob("ex3.jpg")[:30000]):
         with pytest.raises(I2sError):
-            det.jpeg_info(_blob(n))
-        with pytest.raises(I2sError):
-            det.detect_jpeg([_blob(n)], Params(), full=False)
+            det.detect_jpeg([blob], Params(), full=False)
     with pytest.raises(I2sError):
-        det.detect_jpeg([b"\\xff\\xd8 not a jpeg"], Params(), full=False)
-    with pytest.raises(I2sError):
-        det.detect_jpeg([_blob("ex9.jpg")[:4000]], Params(), full=False)        # truncated entropy data
+        det.jpeg_info(buf.getvalue())
+    assert det.jpeg_info(_blob("ex1.jpg")) == (750, 747, 1)          # progressive, greyscale
     det.close()
 
 
 def _encode_random(rng):
-    h, w = int(rng.integers(3, 260)), int(rng.integers(3, 260))
+    h, w = int(rng.integers(1, 260)), int(rng.integers(1, 260))
     kind = rng.integers(0, 3)
     if kind == 0:
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -74,7 +73,7 @@ def _encode_random(rng):
     pil = Image.fromarray(img)
     if rng.random() < 0.3:
         pil = pil.convert("L")
-    kw = dict(quality=int(rng.integers(5, 101)), optimize=bool(rng.random() < 0.5))
+    kw = dict(quality=int(rng.integers(5, 101)), optimize=bool(rng.random() < 0.5), progressive=bool(rng.random() < 0.4))
     if pil.mode == "RGB":
         kw["subsampling"] = int(rng.integers(0, 3))                  # 4:4:4, 4:2:2, 4:2:0
     r = rng.random()
@@ -90,8 +89,8 @@ def _encode_random(rng):
 
 @pytest.mark.parametrize("seed", range(24))
 def test_pillow_encoded_images(seed):
-    """Random content and sizes, every encoder setting Pillow offers for sequential JPEGs (subsampling, quality, optimised
-    Huffman tables, restart intervals); every third seed adds the device rotate / crop on top."""
+    """Random content and sizes from 1x1, every encoder setting Pillow offers (subsampling, quality, optimised Huffman tables,
+    restart intervals, progressive scan scripts); every third seed adds the device rotate / crop on top."""
     rng = np.random.default_rng(7000 + seed)
     pairs = [_encode_random(rng) for _ in range(5)]
     blobs, refs = [p[0] for p in pairs], [p[1] for p in pairs]
@@ -127,9 +126,9 @@ def test_multi_pass_scheduled_jpeg_batch():
 
 
 def test_headless_cli_mixed_inputs(tmp_path):
-    """python -m img2sgf_amd with baseline JPEGs (decoded on the device) and a progressive one (opened with Pillow) in one call."""
+    """python -m img2sgf_amd with sequential and progressive JPEGs, all decoded on the device."""
     from img2sgf_amd.__main__ import main
-    names = ["ex7.jpg", "ex1.jpg", "ex9.jpg", "ex13.jpg"]
+    names = ["ex7.jpg", "ex1.jpg", "ex9.jpg", "ex13.jpg"]          # ex1 is progressive
     assert main([os.path.join(GOLDEN, "test_images", n) for n in names] + ["-o", str(tmp_path)]) == 0
     for n in names:
         want = opipe.process_image(opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n)), keep_planes=False)
