@@ -82,12 +82,16 @@ def _encode_random(rng):
     elif r < 0.5:
         kw["restart_marker_rows"] = int(rng.integers(1, 4))
     buf = io.BytesIO()
-    pil.save(buf, "JPEG", **kw)
+    try:
+        pil.save(buf, "JPEG", **kw)
+    except OSError:                       # Pillow's encoder gives up on some option mixes ("Suspension not allowed here")
+        buf = io.BytesIO()
+        pil.save(buf, "JPEG", quality=kw["quality"])
     blob = buf.getvalue()
     return blob, np.array(Image.open(io.BytesIO(blob)).convert("RGB"))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("I2S_JPEG_SEEDS", 24))))
 def test_pillow_encoded_images(seed):
     """Random content and sizes from 1x1, every encoder setting Pillow offers (subsampling, quality, optimised Huffman tables,
     restart intervals, progressive scan scripts); every third seed adds the device rotate / crop on top."""
@@ -100,7 +104,8 @@ def test_pillow_encoded_images(seed):
         for r in refs:
             h, w = r.shape[:2]
             ang = float(rng.uniform(-30, 30))
-            sel = (int(rng.integers(-3, 3)), int(rng.integers(-3, 3)), w - int(rng.integers(-3, 2)), h - int(rng.integers(-3, 2)))
+            x1, y1 = int(rng.integers(-3, 3)), int(rng.integers(-3, 3))
+            sel = (x1, y1, max(x1 + 1, w - int(rng.integers(-3, 2))), max(y1 + 1, h - int(rng.integers(-3, 2))))
             xfs.append(preprocess.xform((w, h), ang, sel))
             wants.append(np.array(Image.fromarray(r).rotate(angle=-ang, fillcolor="white", center=preprocess.rectangle_centre(sel)).crop(sel)))
     det = Detector(0, 5, 310, 310)
