@@ -409,6 +409,31 @@ class StreamedDetector:
                 out[i] = part[j]
         return out
 
+    def detect_jpeg(self, blobs: Sequence[bytes], params: Optional[Params] = None, xforms=None):
+        """JPEG file bytes (Detector.detect_jpeg) over the streams: the passes are formed over the files sorted by pixel count
+        and dealt round-robin, so the host-side Huffman decoding of one stream overlaps the kernels of another."""
+        B, n, mb = len(blobs), len(self.dets), self.max_batch
+        def area(i):
+            if xforms is not None:
+                c = xforms[i][1]
+                return (c[2] - c[0]) * (c[3] - c[1])
+            w, h, _ = jpeg_info(blobs[i], self.dets[0].lib)
+            return w * h
+        order = sorted(range(B), key=area)
+        passes = [order[k:k + mb] for k in range(0, B, mb)]
+        share = [[i for ps in passes[s::n] for i in ps] for s in range(n)]
+        def run(s):
+            idx = share[s]
+            xf = [xforms[i] for i in idx] if xforms is not None else None
+            return self.dets[s].detect_jpeg([blobs[i] for i in idx], params, full=False, xforms=xf)
+        futs = [(s, self.pool.submit(run, s)) for s in range(n) if share[s]]
+        out = (I2sBoard * B)()
+        for s, f in futs:
+            part = f.result()
+            for j, i in enumerate(share[s]):
+                out[i] = part[j]
+        return out
+
     def last_timing(self):
         t = [d.last_timing() for d in self.dets]
         return {k: sum(x[k] for x in t) for k in t[0]}

@@ -138,3 +138,15 @@ def test_headless_cli_mixed_inputs(tmp_path):
     for n in names:
         want = opipe.process_image(opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n)), keep_planes=False)
         assert (tmp_path / n.replace(".jpg", ".sgf")).read_text() == want["sgf"], n
+
+
+def test_streamed_jpeg_batch():
+    from img2sgf_amd.pipeline import StreamedDetector
+    blobs = [_blob(n) for n in IMAGES] * 2
+    det = Detector(0, 8, 1300, 1300)
+    want = [bytes(b) for b in det.detect_jpeg(blobs, Params(contrast=70, brightness=50), full=False)]
+    det.close()
+    sd = StreamedDetector(0, 3, 5, 1300, 1300)
+    got = sd.detect_jpeg(blobs, Params(contrast=70, brightness=50))
+    sd.close()
+    assert [bytes(b) for b in got] == want

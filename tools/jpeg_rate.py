@@ -42,3 +42,14 @@ mpx = sum(i.shape[0] * i.shape[1] for i in imgs) / 1e6
 print("%d JPEGs, %.1f Mpx, %.1f MB of files" % (len(blobs), mpx, sum(len(b) for b in blobs) / 1e6))
 print("Pillow decode (1 thread) %.1f ms + detect_batch %.1f ms = %.0f img/s" % (t_pil * 1e3, t_det * 1e3, len(blobs) / (t_pil + t_det)))
 print("detect_jpeg (1 thread)   %.1f ms                      = %.0f img/s" % (t_dev * 1e3, len(blobs) / t_dev))
+det.close()
+from img2sgf_amd.pipeline import StreamedDetector      # noqa: E402
+for n in (2, 4):
+    sd = StreamedDetector(0, n, 16, 1300, 1300)
+    sd.detect_jpeg(blobs[:16 * n], params)
+    t = time.perf_counter()
+    b3 = sd.detect_jpeg(blobs, params)
+    dt = time.perf_counter() - t
+    assert all(bytes(x) == bytes(y) for x, y in zip(b1, b3))
+    sd.close()
+    print("detect_jpeg, %d streams    %.1f ms                      = %.0f img/s" % (n, dt * 1e3, len(blobs) / dt))
