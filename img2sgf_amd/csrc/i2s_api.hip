@@ -594,20 +594,25 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
     if (!ctx || B < 0 || (B > 0 && (!jpeg || !len || !boards))) return I2S_E_INVALID;
     int rc = check_params(p);
     if (rc) return rc;
-    std::vector<JpegFile> files(B);
+    // every file is checked (and its frame size noted) before anything runs; the parsed tables and scan lists are only kept
+    // for the images of the pass in flight (a progressive file carries ~100 KB of Huffman tables)
+    std::vector<int> fw(B), fh(B);
     for (int i = 0; i < B; i++) {
         if (!jpeg[i]) return I2S_E_INVALID;
-        const int jr = jpg_parse(jpeg[i], len[i], &files[i]);
+        JpegFile f;
+        const int jr = jpg_parse(jpeg[i], len[i], &f);
         if (jr == JPG_BAD) return I2S_E_INVALID;
         if (jr == JPG_UNSUPPORTED) return I2S_E_UNSUPPORTED;
+        fw[i] = f.X; fh[i] = f.Y;
     }
+    std::vector<JpegFile> files;
     I2S_HIP(hipSetDevice(ctx->device));
     // pass formation as in i2s_detect_batch_xf (by processed area when p->schedule is set)
     std::vector<int> order(B);
     for (int i = 0; i < B; i++) order[i] = i;
     if (p->schedule && B > ctx->max_batch) {
         auto area = [&](int i) {
-            return xf ? (long long)(xf[i].crop[2] - xf[i].crop[0]) * (xf[i].crop[3] - xf[i].crop[1]) : (long long)files[i].X * files[i].Y;
+            return xf ? (long long)(xf[i].crop[2] - xf[i].crop[0]) * (xf[i].crop[3] - xf[i].crop[1]) : (long long)fw[i] * fh[i];
         };
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area(a) < area(b); });
     }
@@ -623,10 +628,13 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
     std::vector<int> pw(ctx->max_batch), ph(ctx->max_batch), ps(ctx->max_batch), pc(ctx->max_batch, 3);
     for (int first = 0; first < B; first += ctx->max_batch) {
         const int nb = B - first < ctx->max_batch ? B - first : ctx->max_batch;
+        files.assign(nb, JpegFile());
+        for (int i = 0; i < nb; i++)
+            if (jpg_parse(jpeg[order[first + i]], len[order[first + i]], &files[i]) != JPG_OK) return I2S_E_INVALID;
         // workspace layout of the pass: [coefficients of all images][component planes][RGB images]
         size_t ncoef = 0, nplane = 0, nrgb = 0;
         for (int i = 0; i < nb; i++) {
-            const JpegFile& f = files[order[first + i]];
+            const JpegFile& f = files[i];
             for (int c = 0; c < f.ncomp; c++) {
                 ncoef += align256((size_t)f.c[c].bw * f.c[c].bh * 64 * sizeof(int16_t));
                 nplane += align256((size_t)f.c[c].bw * f.c[c].bh * 64);
@@ -651,7 +659,7 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
         std::vector<size_t> cbytes((size_t)nb * 3, 0);
         for (int i = 0; i < nb; i++) {
             const int k = order[first + i];
-            const JpegFile& f = files[k];
+            const JpegFile& f = files[i];
             JpgDesc& J = ctx->h_jd[i];
             int blocks = 0;
             for (int c = 0; c < 3; c++) {
@@ -682,7 +690,7 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
             std::atomic<int> next(0), bad(-1);
             auto work = [&]() {
                 for (int i = next.fetch_add(1); i < nb; i = next.fetch_add(1)) {
-                    const JpegFile& f = files[order[first + i]];
+                    const JpegFile& f = files[i];
                     int16_t* cp[3] = {cps[(size_t)i * 3], cps[(size_t)i * 3 + 1], cps[(size_t)i * 3 + 2]};
                     for (int c = 0; c < f.ncomp; c++) memset(cp[c], 0, cbytes[(size_t)i * 3 + c]);
                     if (jpg_decode_scan(f, cp) != JPG_OK) bad.store(order[first + i]);
