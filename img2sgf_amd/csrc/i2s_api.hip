@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -576,14 +577,18 @@ extern "C" int i2s_detect_batch(i2s_ctx* ctx, int B, const uint8_t* const* img, 
 extern "C" int i2s_jpeg_info(const uint8_t* data, size_t len, int* w, int* h, int* channels)
 {
     if (!data) return I2S_E_INVALID;
-    JpegFile f;
-    const int rc = jpg_parse(data, len, &f);
-    if (rc == JPG_BAD) return I2S_E_INVALID;
-    if (rc == JPG_UNSUPPORTED) return I2S_E_UNSUPPORTED;
-    if (w) *w = f.X;
-    if (h) *h = f.Y;
-    if (channels) *channels = f.ncomp;
-    return I2S_OK;
+    try {
+        JpegFile f;
+        const int rc = jpg_parse(data, len, &f);
+        if (rc == JPG_BAD) return I2S_E_INVALID;
+        if (rc == JPG_UNSUPPORTED) return I2S_E_UNSUPPORTED;
+        if (w) *w = f.X;
+        if (h) *h = f.Y;
+        if (channels) *channels = f.ncomp;
+        return I2S_OK;
+    } catch (const std::bad_alloc&) {
+        return I2S_E_INVALID;
+    }
 }
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -591,6 +596,7 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* jpeg, const size_t* len, const i2s_xform* xf,
                                      const i2s_params* p, i2s_board* boards, i2s_result* full)
 {
+    try {
     if (!ctx || B < 0 || (B > 0 && (!jpeg || !len || !boards))) return I2S_E_INVALID;
     int rc = check_params(p);
     if (rc) return rc;
@@ -603,6 +609,9 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
         const int jr = jpg_parse(jpeg[i], len[i], &f);
         if (jr == JPG_BAD) return I2S_E_INVALID;
         if (jr == JPG_UNSUPPORTED) return I2S_E_UNSUPPORTED;
+        // sizes are checked before any workspace is sized from them (a hostile header may claim 65535 x 65535)
+        if (!xf && (f.X > ctx->max_w || f.Y > ctx->max_h)) return I2S_E_TOO_LARGE;
+        if (xf && ((long long)f.X * f.Y > (1ll << 26) || f.X >= 32768 || f.Y >= 32768)) return I2S_E_TOO_LARGE;
         fw[i] = f.X; fh[i] = f.Y;
     }
     std::vector<JpegFile> files;
@@ -724,6 +733,10 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
     for (int i = 0; i < 5; i++) ctx->timing[i] = timing[i];
     ctx->last_staged = 1;          // i2s_fetch_source: the decoded (and, if requested, transformed / enhanced) image
     return I2S_OK;
+    } catch (const std::bad_alloc&) {
+        snprintf(ctx->err, sizeof(ctx->err), "out of host memory while decoding JPEG data");
+        return I2S_E_INVALID;
+    }
 }
 
 extern "C" int i2s_classify_batch(i2s_ctx* ctx, int first, int n, const i2s_params* p, i2s_board* boards, i2s_result* full)
