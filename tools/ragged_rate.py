@@ -18,9 +18,10 @@ raws = [preprocess.enhance(preprocess.load_image(os.path.join(GOLDEN, n))) for n
 imgs = raws * 8
 perm = np.random.default_rng(0).permutation(len(imgs))
 mixed = [imgs[i] for i in perm]
-det = Detector(0, 16, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+MB = int(os.environ.get("I2S_RAGGED_PASS", 16))
+det = Detector(0, MB, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
 for name, params in (("input order", Params()), ("scheduled", Params(schedule=True))) * 2:
-    det.detect_batch(mixed[:16], params, full=False)
+    det.detect_batch(mixed[:MB], params, full=False)
     t = time.perf_counter()
     det.detect_batch(mixed, params, full=False)
     dt = time.perf_counter() - t
@@ -30,8 +31,8 @@ det.close()
 from img2sgf_amd.pipeline import StreamedDetector      # noqa: E402
 ref = None
 for n_streams in (2, 3, 4):
-    sd = StreamedDetector(0, n_streams, 16, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
-    sd.detect_batch(mixed[:48])
+    sd = StreamedDetector(0, n_streams, MB, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    sd.detect_batch(mixed[:3 * MB])
     for rep in range(2):
         t = time.perf_counter()
         boards = sd.detect_batch(mixed)
