@@ -221,6 +221,14 @@ struct JpegBits {
     JpegBits(const uint8_t* d_, size_t n_) : d(d_), n(n_) {}
     inline void fill()
     {
+        // fast path: four data bytes without 0xFF (no stuffing, no marker) enter the accumulator at once
+        while (cnt <= 32 && !hit_marker && p + 4 <= n) {
+            const uint32_t w = ((uint32_t)d[p] << 24) | ((uint32_t)d[p + 1] << 16) | ((uint32_t)d[p + 2] << 8) | d[p + 3];
+            const uint32_t inv = ~w;                                 // a byte of w is 0xFF iff the byte of inv is 0
+            if (((inv - 0x01010101u) & ~inv & 0x80808080u) != 0) break;
+            acc = (acc << 32) | w;
+            cnt += 32; p += 4; real_bits += 32;
+        }
         while (cnt <= 56) {
             unsigned b = 0;
             if (!hit_marker && p < n) {
