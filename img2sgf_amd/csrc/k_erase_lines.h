@@ -193,23 +193,22 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     }
     __syncthreads();
     {
+        // every non-zero pixel votes once per angle of the three HoughLines calls: threads stride over the pixels, the angle
+        // rows are a uniform inner loop (no per-item division by the angle count, no select chain over the row table)
         const int nnz = s_n;
-        int nang = 0, rows_of[LROWS];
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-            for (int n = 0; n < trig.n[c]; n++) rows_of[nang++] = c * LANG + n;
-        for (int it = tid; it < nnz * nang; it += 256) {
-            const int pi = it / nang, ai = it - pi * nang;
+        for (int pi = tid; pi < nnz; pi += 256) {
             const int p = s_nz[pi];
-            const int px = x0 + (p & (ET_W - 1)), py = y0 + p / ET_W;
-            int row = rows_of[0];
+            const float fx = (float)(x0 + (p & (ET_W - 1))), fy = (float)(y0 + p / ET_W);
 #pragma unroll
-            for (int q = 1; q < LROWS; q++) if (q == ai) row = rows_of[q];
-            const float a = (float)px * s_cos[row], bb = (float)py * s_sin[row];
-            const int r = __float2int_rn(a + bb);
-            const unsigned bin = (unsigned)(r - s_rmin[row]);
-            if (bin < (unsigned)LB) atomicAdd(&s_hist[row][bin], 1);
-            else atomicAdd(&lacc[((size_t)b * LROWS + row) * lrow + r + half], 1);
+            for (int c = 0; c < 3; c++)
+                for (int n = 0; n < trig.n[c]; n++) {
+                    const int row = c * LANG + n;
+                    const float a = fx * s_cos[row], bb = fy * s_sin[row];
+                    const int r = __float2int_rn(a + bb);
+                    const unsigned bin = (unsigned)(r - s_rmin[row]);
+                    if (bin < (unsigned)LB) atomicAdd(&s_hist[row][bin], 1);
+                    else atomicAdd(&lacc[((size_t)b * LROWS + row) * lrow + r + half], 1);
+                }
         }
     }
     __syncthreads();
