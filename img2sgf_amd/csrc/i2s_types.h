@@ -79,6 +79,13 @@ typedef short v2s __attribute__((vector_size(4)));
 __device__ __forceinline__ v2s pk_from(unsigned u) { v2s r; __builtin_memcpy(&r, &u, 4); return r; }
 __device__ __forceinline__ unsigned pk_bits(v2s v) { unsigned u; __builtin_memcpy(&u, &v, 4); return u; }
 __device__ __forceinline__ v2s pk_abs(v2s a) { const v2s n = -a; return a > n ? a : n; }
+typedef unsigned short v2u __attribute__((vector_size(4)));
+__device__ __forceinline__ v2u pku_from(unsigned u) { v2u r; __builtin_memcpy(&r, &u, 4); return r; }
+__device__ __forceinline__ unsigned pku_bits(v2u v) { unsigned u; __builtin_memcpy(&u, &v, 4); return u; }
+// per-half mask (0xffff / 0) of a > b for packed values below 32768 (signed 16-bit subtract, sign spread)
+__device__ __forceinline__ unsigned pk_gt(unsigned a, unsigned b) { return pk_bits((pk_from(b) - pk_from(a)) >> 15); }
+// bitwise select: m ? a : b
+__device__ __forceinline__ unsigned bsel(unsigned m, unsigned a, unsigned b) { return ((a ^ b) & m) ^ b; }
 
 __device__ __host__ inline int imin(int a, int b) { return a < b ? a : b; }
 __device__ __host__ inline int imax(int a, int b) { return a > b ? a : b; }

@@ -227,45 +227,47 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
         const unsigned mb01 = s_mag[ry * MSTR + 2 * s], mb23 = s_mag[ry * MSTR + 2 * s + 1];
         const int mxall = imax(imax((int)(mb01 & 0xffffu), (int)(mb01 >> 16)), imax((int)(mb23 & 0xffffu), (int)(mb23 >> 16)));
         if (mxall > low) {
+            // Non-maximum suppression of the strip's 4 pixels as two pairs in 16-bit lanes (magnitudes <= 2040, gradients
+            // <= 1020): comparisons are packed subtractions whose sign is spread over the lane; the sector tests
+            // |dy| * 2^15 < |dx| * 13573 and |dy| * 2^15 > |dx| * 79109 become |dy| <= q and |dy| > 2 |dx| + q with
+            // q = floor(|dx| * 13573 / 2^15) = (|dx| * 53 + (|dx| * 5 >> 8)) >> 7 (13573 = 53 * 256 + 5 is odd, so the quotient
+            // is never exact for |dx| > 0, and for |dx| = |dy| = 0 the magnitude is 0 and nothing is kept anyway).
             const unsigned* pg = s_grad + ci * 4;
-            const unsigned gxb[2] = {pg[0], pg[1]}, gyb[2] = {pg[2], pg[3]};
-            // magnitudes of rows ry-1, ry, ry+1 at columns -1 .. 4 of the strip
-            int mg[3][6];
+            unsigned L[3][2], C[3][2], R[3][2];       // per row (above, this, below) and pair: left / centre / right magnitudes
 #pragma unroll
             for (int rr = 0; rr < 3; rr++) {
                 const unsigned* pm = s_mag + (ry - 1 + rr) * MSTR + 2 * s;
                 const unsigned a = pm[-1], b0 = pm[0], b1 = pm[1], c = pm[2];
-                mg[rr][0] = (int)(a >> 16); mg[rr][1] = (int)(b0 & 0xffffu); mg[rr][2] = (int)(b0 >> 16);
-                mg[rr][3] = (int)(b1 & 0xffffu); mg[rr][4] = (int)(b1 >> 16); mg[rr][5] = (int)(c & 0xffffu);
+                C[rr][0] = b0; C[rr][1] = b1;
+                L[rr][0] = __builtin_amdgcn_alignbit(b0, a, 16);
+                R[rr][0] = L[rr][1] = __builtin_amdgcn_alignbit(b1, b0, 16);
+                R[rr][1] = __builtin_amdgcn_alignbit(c, b1, 16);
             }
-            outw = 0; outw0 = 0;
+            const unsigned lowp = (unsigned)(iclamp(low, -1, 4095) & 0xffff) * 0x00010001u;
+            const unsigned highp = (unsigned)(iclamp(high, -1, 4095) & 0xffff) * 0x00010001u;
+            const unsigned high0p = (unsigned)(iclamp(high_main, -1, 4095) & 0xffff) * 0x00010001u;
+            unsigned o16[2], o16m[2];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                // branch-free NMS: evaluate the three sector rules and select (divergent branches cost more than the ALU work)
-                const int mcur = mg[1][q + 1];
-                const unsigned xb = gxb[q >> 1], yb = gyb[q >> 1];
-                const int xs = (q & 1) ? ((int)xb >> 16) : (int)(short)(xb & 0xffffu);
-                const int ys = (q & 1) ? ((int)yb >> 16) : (int)(short)(yb & 0xffffu);
-                const int ax = iabs_(xs), ay = iabs_(ys) << 15;
-                const int tg22x = ax * 13573;
-                const int tg67x = tg22x + (ax << 16);
-                const int c_h = (mcur > mg[1][q]) & (mcur >= mg[1][q + 2]);
-                const int c_v = (mcur > mg[0][q + 1]) & (mcur >= mg[2][q + 1]);
-                // diagonal: s = ((xs ^ ys) < 0) ? -1 : 1 -> compare (row-1, x-s) and (row+1, x+s).  The selection is done with a
-                // bit mask on VALUES (a ?: on array elements gets folded into a dynamic register-array index = an 18-way
-                // select chain).
-                const int msk = (xs ^ ys) >> 31;                // all ones when the signs differ
-                const int ul = mg[0][q], ur = mg[0][q + 2], dl = mg[2][q], dr = mg[2][q + 2];
-                const int d_a = ul ^ ((ul ^ ur) & msk);
-                const int d_b = dr ^ ((dr ^ dl) & msk);
-                const int c_d = (mcur > d_a) & (mcur > d_b);
-                const int keep = (ay < tg22x) ? c_h : ((ay > tg67x) ? c_v : c_d);
-                const int kept = (mcur > low) & keep;
-                const unsigned o = kept ? ((mcur > high) ? 2u : 0u) : 1u;
-                const unsigned o0 = kept ? ((mcur > high_main) ? 2u : 0u) : 1u;
-                outw |= o << (8 * q);
-                outw0 |= o0 << (8 * q);
+            for (int j = 0; j < 2; j++) {
+                const unsigned cur = C[1][j];
+                const unsigned gxp = pg[j], gyp = pg[2 + j];
+                const unsigned c_h = pk_gt(cur, L[1][j]) & ~pk_gt(R[1][j], cur);
+                const unsigned c_v = pk_gt(cur, C[0][j]) & ~pk_gt(C[2][j], cur);
+                // diagonal: signs differ -> (above right, below left), else (above left, below right)
+                const unsigned msk = pk_bits(pk_from(gxp ^ gyp) >> 15);
+                const unsigned c_d = pk_gt(cur, bsel(msk, R[0][j], L[0][j])) & pk_gt(cur, bsel(msk, L[2][j], R[2][j]));
+                const v2u ax = pku_from(pk_bits(pk_abs(pk_from(gxp))));
+                const unsigned ay = pk_bits(pk_abs(pk_from(gyp)));
+                const v2u q = (ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7;
+                const unsigned s22 = ~pk_gt(ay, pku_bits(q));
+                const unsigned s67 = pk_gt(ay, pku_bits(ax + ax + q));
+                const unsigned keep = bsel(s22, c_h, bsel(s67, c_v, c_d));
+                const unsigned kept = keep & pk_gt(cur, lowp);
+                o16[j] = (kept & pk_gt(cur, highp) & 0x00020002u) | (~kept & 0x00010001u);
+                o16m[j] = (kept & pk_gt(cur, high0p) & 0x00020002u) | (~kept & 0x00010001u);
             }
+            outw = __builtin_amdgcn_perm(o16[1], o16[0], 0x06040200u);
+            outw0 = __builtin_amdgcn_perm(o16m[1], o16m[0], 0x06040200u);
         }
         const int off = rowoff(gy, g.pitch) + gx0;
         const unsigned outm = mp0 ? outw0 : outw;                        // the word that is the main Canny's map
