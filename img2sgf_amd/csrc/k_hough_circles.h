@@ -382,11 +382,10 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
     // every wavefront works through its centres on its own: the phases below are separated by wave-level barriers only
     // (LDS operations of one wave complete in order), so the four waves of a workgroup never wait for each other
     for (int c = blockIdx.x * 4 + wave; c < n; c += gridDim.x * 4) {
-        const bool live = true;
         for (int i = lane; i < RAD_BINS_MAX; i += 64) bins[i] = 0;
         __builtin_amdgcn_wave_barrier();
         int cxi = 0, cyi = 0;
-        if (live) {
+        {
             const unsigned e = cent_list[(size_t)bv * CENT_CAP + c];
             cxi = (int)(e & 0xffffu); cyi = (int)(e >> 16);
             // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: at most 3 x 3 bins overlap that box.
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
 #pragma unroll
         for (int q = 0; q < PERL; q++) bins[lane * PERL + q] = loc[q] + excl;
         __builtin_amdgcn_wave_barrier();
-        if (live) {
+        {
             // OpenCV scans the histogram from the top: take the highest non-empty bin u <= j, sum the 10 bins below it
             // (lo = u - 10), compare, continue at j = lo - 1.  WHICH bins get visited depends on the occupancy masks alone, so
             // that part runs as a scalar bit loop, one statically indexed 64-bin word after the other (a dynamically indexed
