@@ -10,7 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
-#include <new>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -586,7 +586,7 @@ extern "C" int i2s_jpeg_info(const uint8_t* data, size_t len, int* w, int* h, in
         if (h) *h = f.Y;
         if (channels) *channels = f.ncomp;
         return I2S_OK;
-    } catch (const std::bad_alloc&) {
+    } catch (const std::exception&) {
         return I2S_E_INVALID;
     }
 }
@@ -708,7 +708,9 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
             unsigned hw = std::thread::hardware_concurrency();
             const int nthreads = std::max(1, std::min({nb, (int)(hw ? hw : 1), 16}));
             std::vector<std::thread> pool;
-            for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
+            for (int t = 1; t < nthreads; t++) {
+                try { pool.emplace_back(work); } catch (const std::exception&) { break; }      // carry on with the threads we have
+            }
             work();
             for (auto& t : pool) t.join();
             if (bad.load() >= 0) {
@@ -733,8 +735,8 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
     for (int i = 0; i < 5; i++) ctx->timing[i] = timing[i];
     ctx->last_staged = 1;          // i2s_fetch_source: the decoded (and, if requested, transformed / enhanced) image
     return I2S_OK;
-    } catch (const std::bad_alloc&) {
-        snprintf(ctx->err, sizeof(ctx->err), "out of host memory while decoding JPEG data");
+    } catch (const std::exception& e) {               // bad_alloc, a thread that could not be started ...: nothing crosses the C ABI
+        snprintf(ctx->err, sizeof(ctx->err), "host failure while decoding JPEG data: %s", e.what());
         return I2S_E_INVALID;
     }
 }
