@@ -3,17 +3,27 @@
 
 A step = one pass of the whole hot path (grey -> blur bank -> Canny -> 10x HoughCircles -> erase -> HoughLines ->
 grid -> classifier) over one batch of synthetic diagrams resident in HBM, per rank; ranks own disjoint seed ranges
-(no data-path collective), then all-gather the 384-byte board records over RCCL.  Prints one JSON line.
+(no data-path collective); the only exchange is one all-gather of the 384-byte board records.  Prints one JSON line.
 
-Workload (BASELINE.json configs[2]): 4096 synthetic 1024x1024 19x19 diagrams per GPU, seeds rank*4096 .. +4095.
-The timed region drives `--streams` HIP streams per GPU (independent contexts; the latency-bound tail kernels of one
-slice overlap the throughput-bound kernels of another).  The roofline object is measured separately, right after the
-timed region, on ONE stream (concurrent streams would stretch every per-kernel duration): HIP events recorded on the
-context's stream around the blur+Canny stage, `--roofline-images` diagrams of the same workload.
+Launch: `python bench.py --gpus N` starts the N ranks itself (re-executes under `python -m torch.distributed.run
+--nproc-per-node N`, rendezvous on 127.0.0.1); started by torch.distributed.run directly (RANK / WORLD_SIZE in the
+environment) it is one rank of that job.  With ranks, the records are all-gathered DEVICE TO DEVICE over RCCL through
+the C ABI (`i2s_comm_create` / `i2s_set_board_sink` / `i2s_allgather_boards`): detect calls leave their records in the
+rank's shard of the gather buffer on the GPU, `ncclAllGather` runs in place on the context's stream, one D2H copy
+delivers the table.  `n_gpus` in the output is the number of ranks RCCL saw.
+
+Workload (BASELINE.json configs[2]; configs[3] at --gpus 8): 4096 synthetic 1024x1024 19x19 diagrams per GPU, seeds
+rank*4096 .. +4095.  The timed region drives `--streams` HIP streams per GPU (independent contexts; the latency-bound
+tail kernels of one slice overlap the throughput-bound kernels of another).  The roofline objects are measured
+separately, right after the timed region, on ONE stream (concurrent streams would stretch every per-kernel duration):
+HIP events recorded on the context's stream in front of every kernel, `--roofline-images` diagrams of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,25 +36,56 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # same guide: measured copy ceiling
 N_PIX = 1024 * 1024
 BLUR_CANNY_BYTES = 14 * N_PIX  # Canny 2N + 3 Gaussians 6N + 3 medians 6N, unfused accounting
+# conflict-free LDS-atomic ceiling of one MI355X (profiles/r01_g_lds_atomic_microbench.txt): 13.5 lanes per CU-cycle
+LDS_ATOMIC_PEAK = 13.5 * 256 * 2.4e9
+BLUR_CANNY_SEGS = ("k_grey", "k_median3", "k_median57", "k_gauss357", "k_blur", "k_sobel_nms(main Canny)",
+                   "k_hysteresis(main Canny)")
 
 
 def cpu_baseline(per_worker):
-    """The oracle (CPU restatement of the reference's OpenCV path + the reference's glue) on the host cores: one
-    single-threaded worker process per core (tools/cpu_baseline.py, run in its own interpreter so that the workers fork
-    without a HIP runtime in the parent), on a bounded sample of the same workload."""
-    import subprocess
+    """tools/cpu_baseline.py in its own interpreter (its workers fork; no HIP runtime in their parent): the reference's
+    ten cv2 calls + glue when cv2 is importable (kind "cv2": B1 = 1 process with OpenCV's own thread pool, B2 = one
+    single-threaded process per core), otherwise the oracle (kind "port") on every host core; bounded sample."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--per-worker", str(per_worker)],
-                         stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, check=True, timeout=900).stdout
+                         stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, check=True, timeout=1200).stdout
     return json.loads(out.decode().strip().splitlines()[-1])
 
 
+def kernels_sha():
+    """Hash of the kernel sources: PMC traffic figures are only valid for the kernels they were collected on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "img2sgf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic():
-    """HBM bytes per image of the blur+Canny stage from the committed PMC passes (profiles/), or None."""
+    """(HBM bytes per image of the blur+Canny stage, provenance) from the committed PMC passes (profiles/traffic.json,
+    written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command).
+    None -- not a stale number -- when the kernels changed since the counters were collected."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
-        with open(p) as f:
-            return json.load(f).get("blur_canny_hbm_bytes_per_image")
-    return None
+    if not os.path.exists(p):
+        return None, {"file": None}
+    with open(p) as f:
+        t = json.load(f)
+    src = {"file": "profiles/traffic.json", "kernels_sha_of_counters": t.get("kernels_sha"), "kernels_sha_now": kernels_sha()}
+    if t.get("kernels_sha") != src["kernels_sha_now"]:
+        src["stale"] = True
+        return None, src
+    return t.get("blur_canny_hbm_bytes_per_image"), src
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks (one per GPU) and pass their output on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -60,6 +101,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+
     import torch
     import torch.distributed as dist
     from img2sgf_amd import synth, dist as i2s_dist
@@ -68,27 +112,42 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    use_dist = world > 1 or "RANK" in os.environ        # launched by torch.distributed.run: always go through RCCL
+    use_dist = "RANK" in os.environ                     # a rank of a torch.distributed.run job: always go through RCCL
+    if use_dist and world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting the ranks that exist" % (args.gpus, world),
+              file=sys.stderr)
+    gather = None
+    torch.cuda.set_device(local)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
+        world = dist.get_world_size()
+        # the library's own RCCL communicator for the board records: rank 0's unique id travels over torch's
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(i2s_dist.BoardGather.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        gather = i2s_dist.BoardGather(local, world, rank, args.batch * world, bytes(uid.cpu().numpy().tobytes()))
     B = args.batch
-    lo, hi = i2s_dist.shard_range(B * world, rank, world)
+    total = B * world
+    lo, hi = i2s_dist.shard_range(total, rank, world)
     dev, occs = synth.synth_batch_torch(range(lo, hi), torch.device("cuda", local))   # rendered on the GPU, resident in HBM
     torch.cuda.synchronize()
     pass_size = min(args.pass_size, B)
     if args.streams > 1:
         det = StreamedDetector(local, args.streams, pass_size, 1024, 1024)
+        det0 = det.dets[0]
     else:
-        det = Detector(local, pass_size, 1024, 1024)
+        det = det0 = Detector(local, pass_size, 1024, 1024)
     params = Params()
 
     def step():
-        boards = det.detect_device(dev, params)
-        return i2s_dist.allgather_boards(boards, world, local)
+        if gather is None:
+            return i2s_dist.boards_to_numpy(det.detect_device(dev, params)).copy()
+        det.detect_device(dev, params, sink=gather.sink(0))       # records stay on the device, in this rank's shard
+        return gather.allgather(det0)                             # ncclAllGather in place + one D2H of the whole table
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,44 +167,68 @@ def main():
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # sanity: the boards this rank produced equal the generator's occupancy
+    # sanity: every rank holds the whole table, and the boards this rank produced equal the generator's occupancy
+    assert allb.shape == (total, 384)
     mine = allb[lo:hi]
     ok = bool((mine[:, :361].reshape(-1, 19, 19) == occs).all())
+    if use_dist:
+        t = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item())
     det.close()
 
-    out = None
     if rank == 0:
-        # roofline of the blur+Canny stage: one stream, HIP events around the stage on that stream
+        # rooflines: one stream, a HIP event on that stream in front of every kernel
         nr = min(args.roofline_images, B)
         d1 = Detector(local, min(pass_size, nr), 1024, 1024)
+        d1.set_profiling(True)
         d1.detect_device(dev[:nr], params)
         d1.detect_device(dev[:nr], params)
         timing = d1.last_timing()
+        seg = d1.last_kernel_timing()
+        # votes of the HoughCircles stage on this workload: sum of the debug accumulators of a few of the same diagrams
+        nv = min(4, nr)
+        d1.set_debug(True)
+        imgs = dev[:nv].cpu().numpy()
+        d1.detect_batch(list(imgs), params, full=False)
+        votes = sum(int(d1.fetch_circle_acc(i, v).sum()) for i in range(nv) for v in range(8)) / nv
         d1.close()
-        stage_s = timing["blur_canny_ms"] * 1e-3
+        stage_s = sum(seg.get(k, 0.0) for k in BLUR_CANNY_SEGS) * 1e-3
         ach = BLUR_CANNY_BYTES * nr / stage_s / 1e9
-        traffic = measured_traffic()
-        images = B * world * args.steps
+        traffic, traffic_src = measured_traffic()
+        vote_s = seg["k_vote_centres"] * 1e-3
+        images = total * args.steps
         out = {
             "metric": "go-diagram images/sec (1024x1024 greyscale)", "value": images / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU (BASELINE configs[2]), "
-                                   "device-resident, full hot path incl. board all-gather" % B,
-                       "pass_size": pass_size, "streams": args.streams, "boards_match_generator": ok},
+            "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU (BASELINE configs[%d]), "
+                                   "device-resident, full hot path incl. board all-gather" % (B, 2 if world == 1 else 3),
+                       "pass_size": pass_size, "streams": args.streams, "boards_match_generator": ok,
+                       "rccl_ranks": world if use_dist else 0,
+                       "allgather": "ncclAllGather of device-resident records through the C ABI" if use_dist else "single process: none"},
             "roofline": {"bound": "hbm",
-                         "kernel": "blur+Canny stage: k_grey, k_median3, k_median57, k_gauss357, k_sobel_nms_planes(main), "
-                                   "k_hysteresis(map 0); the main-Canny pass also emits HoughCircles' Canny map of the grey plane",
+                         "kernel": "blur+Canny stage: " + ", ".join(k for k in BLUR_CANNY_SEGS if k in seg),
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,
                          "stage_us_per_image": stage_s / nr * 1e6,
-                         "measured_on": "1 stream, %d diagrams, HIP events on the context's stream" % nr},
+                         "measured_on": "1 stream, %d diagrams, HIP events on the context's stream in front of every kernel" % nr},
+            "roofline_k5": {"bound": "lds-atomic", "kernel": "k_vote_centres (HoughCircles accumulator, 8 variants per image)",
+                            "votes_per_image": votes, "achieved": votes * nr / vote_s, "peak": LDS_ATOMIC_PEAK, "unit": "votes/s",
+                            "frac": votes * nr / vote_s / LDS_ATOMIC_PEAK,
+                            "peak_source": "tools/micro/lds_atomic_bench.hip: 13.5 conflict-free atomic lanes per CU-cycle x 256 CUs x 2.4 GHz",
+                            "us_per_image": vote_s / nr * 1e6,
+                            "hough_circles_stage_us_per_image": timing["hough_circles_ms"] * 1e3 / nr},
+            "kernel_us_per_image": {k: v * 1e3 / nr for k, v in seg.items()},
             "single_stream_stage_ms": timing,
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_per_worker)
         print(json.dumps(out))
+        sys.stdout.flush()
+    if gather is not None:
+        gather.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

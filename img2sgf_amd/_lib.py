@@ -87,7 +87,13 @@ assert C.sizeof(I2sResult) == 73384
 EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
            "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_jpeg_info", "i2s_detect_jpeg_batch",
            "i2s_classify_batch", "i2s_grid_from_lines",
-           "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc"]
+           "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc",
+           "i2s_comm_unique_id", "i2s_comm_create", "i2s_comm_destroy", "i2s_comm_last_error", "i2s_comm_shard", "i2s_comm_all",
+           "i2s_set_board_sink", "i2s_allgather_boards",
+           "i2s_set_profiling", "i2s_last_kernel_timing", "i2s_kernel_timing_name"]
+NSEG = 14
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
 
 
 class I2sError(RuntimeError):
@@ -136,7 +142,23 @@ class I2sLibrary:
         L.i2s_set_debug.argtypes = [vp, C.c_int]
         L.i2s_fetch_circle_acc.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.i2s_fetch_line_acc.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_size_t, ip, ip]
-        if L.i2s_abi_version() != 1:
+        L.i2s_comm_unique_id.argtypes = [u8p]
+        L.i2s_comm_create.argtypes = [C.POINTER(vp), C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+        L.i2s_comm_destroy.argtypes = [vp]
+        L.i2s_comm_destroy.restype = None
+        L.i2s_comm_last_error.argtypes = [vp]
+        L.i2s_comm_last_error.restype = C.c_char_p
+        L.i2s_comm_shard.argtypes = [vp]
+        L.i2s_comm_shard.restype = vp
+        L.i2s_comm_all.argtypes = [vp]
+        L.i2s_comm_all.restype = vp
+        L.i2s_set_board_sink.argtypes = [vp, vp]
+        L.i2s_allgather_boards.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+        L.i2s_set_profiling.argtypes = [vp, C.c_int]
+        L.i2s_last_kernel_timing.argtypes = [vp, f32p]
+        L.i2s_kernel_timing_name.argtypes = [C.c_int]
+        L.i2s_kernel_timing_name.restype = C.c_char_p
+        if L.i2s_abi_version() != ABI_VERSION:
             raise I2sError("ABI version mismatch in %s" % path)
 
 

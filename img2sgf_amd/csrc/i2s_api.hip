@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "i2s_types.h"
+#include "comm_rccl.h"
 #include "k_canny.h"
 #include "k_erase_lines.h"
 #include "k_filters.h"
@@ -69,14 +70,25 @@ struct i2s_ctx {
     i2s_result* d_res = nullptr;
     i2s_board* d_boards = nullptr;
     i2s_board* h_boards = nullptr;
+    i2s_board* d_sink = nullptr;    // i2s_set_board_sink: device array that also receives image i's record at [i]
     int* d_dbg_acc = nullptr;
     int debug = 0;
     int hyst_passes = 6;
     int last_nb = 0;
     HoughTrig last_trig{};
     float timing[5] = {0, 0, 0, 0, 0};
+    int prof = 0;                   // i2s_set_profiling: per-kernel HIP events on the stream
+    hipEvent_t pev[I2S_NSEG + 1] = {};
+    float seg_ms[I2S_NSEG] = {};
     char err[256] = {0};
 };
+
+// segments of i2s_last_kernel_timing, in launch order
+static const char* const kSegName[I2S_NSEG] = {
+    "k_grey", "k_median3", "k_median57", "k_gauss357", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
+    "k_sobel_nms_planes(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
+    "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
+#define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
 
 #define I2S_HIP(call)                                                                                   \
     do {                                                                                                \
@@ -142,6 +154,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd};
     for (void* q : host) if (q) (void)hipHostFree(q);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i <= I2S_NSEG; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -371,16 +384,21 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         const dim3 g_row((unsigned)rx * ry * nb), g_f((unsigned)fx * fy * nb), g_m((unsigned)mx * my * nb);
 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
+        I2S_SEG(0);
         hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
+        I2S_SEG(1);
         hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
+        I2S_SEG(2);
         hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                            plane_ptr(ctx, I2S_PLANE_MEDIAN7), mx, my);
+        I2S_SEG(3);
         hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3),
                            plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
         const int ngx = cdiv(fx, NMS_TPB);                             // groups of NMS_TPB tiles along x
         // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
         // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
         const bool fused0 = has_c1 && p->canny_lo == hc_lo;
+        I2S_SEG(4);
         if (fused0)
             hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
                                p->hc_param1, p->canny_hi, 2, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
@@ -388,16 +406,21 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
                                p->canny_lo, p->canny_hi, p->canny_hi, 1, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
         if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
+        I2S_SEG(5);
         rc = run_hysteresis(ctx, 0, fx * fy * nb);
         if (rc) return rc;
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
+        I2S_SEG(6);
         const int v_first = fused0 ? 1 : 0;
         hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb * (NVAR - v_first)), b256, 0, st, ctx->d_desc, g, grey, map0,
                            (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, 0, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
+        I2S_SEG(7);
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;
+        I2S_SEG(8);
         hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
                            ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
+        I2S_SEG(9);
         // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
         if (p->hc_max_radius - p->hc_min_radius + 1 == 30)
             hipLaunchKernelGGL((k_vote_centres<30>), dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
@@ -407,12 +430,15 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             hipLaunchKernelGGL((k_vote_centres<0>), dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
                                ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
                                ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+        I2S_SEG(10);
         hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                            ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
                            ctx->d_est_keys, est_count(ctx));
+        I2S_SEG(11);
         hipLaunchKernelGGL(k_circles_final, dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx),
                            p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));
+        I2S_SEG(12);
 
         hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, ctx->d_desc, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res,
                            ctx->d_tl_cnt, ctx->d_tl_idx);
@@ -420,11 +446,17 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                            plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, fx, fy, ctx->d_tl_cnt, ctx->d_tl_idx);
         hipLaunchKernelGGL(k_line_peaks, dim3(nb), b256, 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
+        I2S_SEG(13);
 
         hipLaunchKernelGGL(k_grid, dim3(nb), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, grey, gp, 1, ctx->d_res, ctx->d_boards);
         I2S_HIP(hipEventRecord(ctx->ev[4], st));
+        I2S_SEG(14);
 
         I2S_HIP(hipMemcpyAsync(ctx->h_boards, ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToHost, st));
+        if (ctx->d_sink && dense)
+            I2S_HIP(hipMemcpyAsync(ctx->d_sink + dst[0], ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToDevice, st));
+        else if (ctx->d_sink) for (int i = 0; i < nb; i++)
+            I2S_HIP(hipMemcpyAsync(ctx->d_sink + dst[i], ctx->d_boards + i, sizeof(i2s_board), hipMemcpyDeviceToDevice, st));
         if (full && dense) I2S_HIP(hipMemcpyAsync(full + dst[0], ctx->d_res, nb * sizeof(i2s_result), hipMemcpyDeviceToHost, st));
         else if (full) for (int i = 0; i < nb; i++)
             I2S_HIP(hipMemcpyAsync(full + dst[i], ctx->d_res + i, sizeof(i2s_result), hipMemcpyDeviceToHost, st));
@@ -446,6 +478,10 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     }
     I2S_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
     ctx->timing[4] += ms;
+    if (ctx->prof) for (int i = 0; i < I2S_NSEG; i++) {
+        I2S_HIP(hipEventElapsedTime(&ms, ctx->pev[i], ctx->pev[i + 1]));
+        ctx->seg_ms[i] += ms;
+    }
     ctx->last_nb = nb;
     ctx->last_staged = (!p->inputs_on_device || p->contrast >= 0 || p->brightness >= 0) ? 1 : 0;
     return I2S_OK;
@@ -487,6 +523,7 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
     }
     I2S_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < 5; i++) ctx->timing[i] = 0;
+    for (int i = 0; i < I2S_NSEG; i++) ctx->seg_ms[i] = 0;
     // pass formation: input order, or (ragged batches) ascending processed area so that similar sizes share a pass
     std::vector<int> order(B);
     for (int i = 0; i < B; i++) order[i] = i;
@@ -836,6 +873,24 @@ extern "C" int i2s_last_timing(const i2s_ctx* ctx, float ms[5])
     return I2S_OK;
 }
 
+extern "C" int i2s_set_profiling(i2s_ctx* ctx, int on)
+{
+    if (!ctx) return I2S_E_INVALID;
+    I2S_HIP(hipSetDevice(ctx->device));
+    if (on) for (int i = 0; i <= I2S_NSEG; i++) if (!ctx->pev[i]) I2S_HIP(hipEventCreate(&ctx->pev[i]));
+    ctx->prof = on ? 1 : 0;
+    return I2S_OK;
+}
+
+extern "C" int i2s_last_kernel_timing(const i2s_ctx* ctx, float ms[I2S_NSEG])
+{
+    if (!ctx || !ms || !ctx->prof) return I2S_E_INVALID;
+    for (int i = 0; i < I2S_NSEG; i++) ms[i] = ctx->seg_ms[i];
+    return I2S_OK;
+}
+
+extern "C" const char* i2s_kernel_timing_name(int i) { return i >= 0 && i < I2S_NSEG ? kSegName[i] : ""; }
+
 extern "C" int i2s_fetch_circle_acc(i2s_ctx* ctx, int index, int variant, int32_t* dst)
 {
     if (!ctx || !dst || !ctx->d_dbg_acc || index < 0 || index >= ctx->last_nb || variant < 0 || variant >= NVAR) return I2S_E_INVALID;
@@ -857,5 +912,92 @@ extern "C" int i2s_fetch_line_acc(i2s_ctx* ctx, int index, int32_t* dst, size_t 
     I2S_HIP(hipStreamSynchronize(ctx->stream));
     if (numrho) *numrho = nr;
     if (nangles) { nangles[0] = ctx->last_trig.n[0]; nangles[1] = ctx->last_trig.n[1]; nangles[2] = ctx->last_trig.n[2]; }
+    return I2S_OK;
+}
+
+// ---- multi-GPU: all-gather of the board records over RCCL (no reference counterpart) ---------------------------------
+
+extern "C" int i2s_set_board_sink(i2s_ctx* ctx, i2s_board* d_sink)
+{
+    if (!ctx) return I2S_E_INVALID;
+    ctx->d_sink = d_sink;
+    return I2S_OK;
+}
+
+extern "C" int i2s_comm_unique_id(uint8_t id[I2S_COMM_ID_BYTES])
+{
+    if (!id) return I2S_E_INVALID;
+    RcclApi* api = rccl_api();
+    if (!api) return I2S_E_NO_DEVICE;
+    RcclId u;
+    memset(&u, 0, sizeof(u));
+    if (api->GetUniqueId(&u) != 0) return I2S_E_HIP;
+    memcpy(id, u.internal, I2S_COMM_ID_BYTES);
+    return I2S_OK;
+}
+
+extern "C" const char* i2s_comm_last_error(const i2s_comm* comm) { return comm ? comm->err : "null communicator"; }
+
+extern "C" void i2s_comm_destroy(i2s_comm* comm)
+{
+    if (!comm) return;
+    (void)hipSetDevice(comm->device);
+    RcclApi* api = rccl_api();
+    if (comm->comm && api) (void)api->CommDestroy(comm->comm);
+    if (comm->d_all) (void)hipFree(comm->d_all);
+    delete comm;
+}
+
+extern "C" int i2s_comm_create(i2s_comm** out, int device_id, const uint8_t id[I2S_COMM_ID_BYTES], int world, int rank, int records_per_rank)
+{
+    if (!out || !id || device_id < 0 || world < 1 || rank < 0 || rank >= world || records_per_rank < 1 ||
+        (long long)world * records_per_rank > (1ll << 24))
+        return I2S_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id >= ndev) return I2S_E_NO_DEVICE;
+    RcclApi* api = rccl_api();
+    if (!api) return I2S_E_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return I2S_E_NO_DEVICE;
+    i2s_comm* c = new i2s_comm();
+    c->device = device_id; c->world = world; c->rank = rank; c->cap = records_per_rank;
+    const size_t bytes = (size_t)world * records_per_rank * sizeof(i2s_board);
+    if (hipMalloc(&c->d_all, bytes) != hipSuccess || hipMemset(c->d_all, 0, bytes) != hipSuccess) { i2s_comm_destroy(c); return I2S_E_HIP; }
+    RcclId u;
+    memcpy(u.internal, id, I2S_COMM_ID_BYTES);
+    const int r = api->CommInitRank(&c->comm, world, u, rank);       // collective: every rank of the job calls it
+    if (r != 0) {
+        fprintf(stderr, "i2s_comm_create: ncclCommInitRank failed: %s\n", api->GetErrorString(r));
+        c->comm = nullptr;
+        i2s_comm_destroy(c);
+        return I2S_E_HIP;
+    }
+    *out = c;
+    return I2S_OK;
+}
+
+extern "C" i2s_board* i2s_comm_shard(i2s_comm* comm) { return comm ? comm->d_all + (size_t)comm->rank * comm->cap : nullptr; }
+extern "C" i2s_board* i2s_comm_all(i2s_comm* comm) { return comm ? comm->d_all : nullptr; }
+
+extern "C" int i2s_allgather_boards(i2s_ctx* ctx, i2s_comm* comm, const i2s_board* d_boards, int n_local, i2s_board* d_all, i2s_board* h_all)
+{
+    if (!ctx || !comm || n_local < 0 || n_local > comm->cap || ctx->device != comm->device) return I2S_E_INVALID;
+    RcclApi* api = rccl_api();
+    if (!api) return I2S_E_NO_DEVICE;
+    I2S_HIP(hipSetDevice(ctx->device));
+    i2s_board* shard = i2s_comm_shard(comm);
+    if (!d_boards) d_boards = shard;
+    if (!d_all) d_all = comm->d_all;
+    // every rank sends comm->cap records (shards differ by at most one image); the unused tail of the own shard is zeroed
+    if (d_boards == shard && n_local < comm->cap)
+        I2S_HIP(hipMemsetAsync(shard + n_local, 0, (size_t)(comm->cap - n_local) * sizeof(i2s_board), ctx->stream));
+    const int r = api->AllGather(d_boards, d_all, (size_t)comm->cap * sizeof(i2s_board), 1 /* ncclUint8 */, comm->comm, ctx->stream);
+    if (r != 0) {
+        snprintf(ctx->err, sizeof(ctx->err), "ncclAllGather failed: %s", api->GetErrorString(r));
+        snprintf(comm->err, sizeof(comm->err), "%s", ctx->err);
+        return I2S_E_HIP;
+    }
+    if (h_all) I2S_HIP(hipMemcpyAsync(h_all, d_all, (size_t)comm->world * comm->cap * sizeof(i2s_board), hipMemcpyDeviceToHost, ctx->stream));
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
     return I2S_OK;
 }

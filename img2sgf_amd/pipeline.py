@@ -246,9 +246,20 @@ class Detector:
             return boards
         return [_detection_from_result(r) for r in res]
 
-    def detect_device(self, batch, params: Optional[Params] = None):
+    def set_board_sink(self, device_ptr):
+        """Detect calls then also leave image i's 384-byte record at device_ptr + 384 i ON THE DEVICE (None / 0 = off):
+        how a rank's shard of the multi-GPU gather buffer is filled without touching the host (dist.BoardGather.sink)."""
+        self._check(self.lib.dll.i2s_set_board_sink(self._ctx, C.c_void_p(int(device_ptr) if device_ptr else None)))
+
+    def detect_device(self, batch, params: Optional[Params] = None, sink=None):
         """batch: a torch uint8 tensor (B,H,W) or (B,H,W,3) resident on this context's GPU.  Returns (B,) I2sBoard
-        array; the pixels are read in place (no copy)."""
+        array; the pixels are read in place (no copy).  sink: see set_board_sink (for this call only)."""
+        if sink is not None:
+            self.set_board_sink(sink)
+            try:
+                return self.detect_device(batch, params)
+            finally:
+                self.set_board_sink(None)
         params = params or Params()
         assert batch.is_cuda and batch.is_contiguous() and str(batch.dtype) == "torch.uint8"
         B, H, W = batch.shape[:3]
@@ -322,6 +333,17 @@ class Detector:
         return dict(blur_canny_ms=ms[0], hough_circles_ms=ms[1], erase_lines_ms=ms[2], grid_ms=ms[3], total_ms=ms[4])
 
 
+    def set_profiling(self, on=True):
+        """Per-kernel HIP events on this context's stream (include/i2s.h: i2s_set_profiling)."""
+        self._check(self.lib.dll.i2s_set_profiling(self._ctx, 1 if on else 0))
+
+    def last_kernel_timing(self):
+        """{kernel group: ms} of the last detect call, in launch order (profiling must be on)."""
+        ms = (C.c_float * _lib.NSEG)()
+        self._check(self.lib.dll.i2s_last_kernel_timing(self._ctx, ms))
+        return {self.lib.dll.i2s_kernel_timing_name(i).decode(): float(ms[i]) for i in range(_lib.NSEG)}
+
+
 class StreamedDetector:
     """n_streams independent contexts (one HIP stream + workspace each) on one GPU, driven from n_streams host threads
     (ctypes releases the GIL during the C call).  A device-resident batch is split into contiguous slices, one per
@@ -336,45 +358,15 @@ class StreamedDetector:
 
     def jpeg_info(self, data: bytes):
         """(w, h, components) of a JPEG the device path can decode; raises I2sError (unsupported / invalid) otherwise."""
-        return jpeg_info(data, self.lib)
+        return jpeg_info(data, self.dets[0].lib)
 
-    def detect_jpeg(self, blobs: Sequence[bytes], params: Optional[Params] = None, full=True, xforms=None):
-        """blobs: the bytes of JPEG files (8-bit, Huffman-coded, sequential or progressive).  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
-        (Huffman stage on the host), bit-exact with Pillow; then as detect_batch (xforms / Params.contrast / .brightness apply
-        to the decoded image).  Raises I2sError("parameter outside the supported envelope") for CMYK, arithmetic-coded
-        and other flavours -- decode those with Pillow and call detect_batch."""
-        params = params or Params()
-        B = len(blobs)
-        arr = (C.c_char_p * B)(*blobs)
-        lens = (C.c_size_t * B)(*[len(b) for b in blobs])
-        boards = (I2sBoard * B)()
-        res = (I2sResult * B)() if full else None
-        xf = None
-        if xforms is not None:
-            xf = (I2sXform * B)()
-            for i, (aff, crop) in enumerate(xforms):
-                xf[i].affine[:] = [float(v) for v in aff]
-                xf[i].crop[:] = [int(v) for v in crop]
-            shapes = [(x.crop[3] - x.crop[1], x.crop[2] - x.crop[0]) for x in xf]
-        else:
-            shapes = [self.jpeg_info(b)[1::-1] for b in blobs]
-        p = params.to_c()
-        self._check(self.lib.dll.i2s_detect_jpeg_batch(self._ctx, B, arr, lens, xf, C.byref(p), boards, res))
-        n_last = (B - 1) % self.max_batch + 1 if B else 0
-        if params.schedule and B > self.max_batch:
-            order = sorted(range(B), key=lambda i: shapes[i][0] * shapes[i][1])
-            self._last_shapes = [shapes[i] for i in order[B - n_last:]]
-        else:
-            self._last_shapes = shapes[B - n_last:]
-        if not full:
-            return boards
-        return [_detection_from_result(r) for r in res]
-
-    def detect_device(self, batch, params: Optional[Params] = None):
+    def detect_device(self, batch, params: Optional[Params] = None, sink=None):
+        """sink: device address of the record of batch[0] (Detector.set_board_sink); every slice deposits at its offset."""
         n = len(self.dets)
         B = batch.shape[0]
         cuts = [B * i // n for i in range(n + 1)]
-        futs = [self.pool.submit(self.dets[i].detect_device, batch[cuts[i]:cuts[i + 1]], params)
+        futs = [self.pool.submit(self.dets[i].detect_device, batch[cuts[i]:cuts[i + 1]], params,
+                                 None if sink is None else sink + cuts[i] * C.sizeof(I2sBoard))
                 for i in range(n) if cuts[i + 1] > cuts[i]]
         out = (I2sBoard * B)()
         pos = 0

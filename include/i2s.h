@@ -22,6 +22,10 @@
  *                         the device (Huffman stage on the host).
  *   i2s_fetch_source      input_image_np 150 after the on-device rotate / crop (110-114) and contrast / brightness
  *                         (141-149) steps, if enabled.
+ *   i2s_comm_* / i2s_allgather_boards / i2s_set_board_sink
+ *                         no reference counterpart (the reference is one process): BASELINE.json's multi-GPU row -- batches
+ *                         shard by image index across the GPUs of a node, one process per GPU, and the 384-byte board
+ *                         records (what to_SGF 781-810 consumes) are all-gathered device to device over RCCL / xGMI.
  *   i2s_fetch_plane       the numpy images the GUI draws: grey_image_np 153,
  *                         edge_detected_image_np 162, the blur bank 171-175,
  *                         circles_removed_image_np 169-198.
@@ -42,7 +46,7 @@
 extern "C" {
 #endif
 
-#define I2S_ABI_VERSION 1
+#define I2S_ABI_VERSION 2
 
 #define I2S_BOARD_SIZE 19      /* img2sgf.py:43 */
 #define I2S_NSLOTS 10          /* blur-bank slots, img2sgf.py:171-175 */
@@ -232,6 +236,43 @@ int  i2s_fetch_source(i2s_ctx* ctx, int index, uint8_t* dst, size_t dst_stride);
  * [1] Hough circles x8 (their Sobel/Canny, votes, centres, radii, min-dist), [2] erase + Hough lines,
  * [3] grid + classifier, [4] total. */
 int  i2s_last_timing(const i2s_ctx* ctx, float ms[5]);
+
+/* ---- multi-GPU: one process per GPU, contiguous shards of the batch, no data-path collective; the only
+ * exchange is ONE all-gather of the i2s_board records, device-resident on both sides, over RCCL (xGMI inside a node).
+ *   rank 0:      i2s_comm_unique_id(id), then hand the 128 bytes to every rank by any host channel (torch.distributed
+ *                broadcast, a file, MPI ...);
+ *   every rank:  i2s_comm_create(&comm, device, id, world, rank, records_per_rank)  -- collective (ncclCommInitRank);
+ *                the communicator owns a device buffer [world][records_per_rank] of records; i2s_comm_shard() is this
+ *                rank's part of it, i2s_comm_all() the whole;
+ *                i2s_set_board_sink(ctx, shard + first)  -- detect calls of ctx then also leave image i's record at
+ *                sink[i] on the device (NULL switches it off), so a batch detected by several contexts / calls lands in
+ *                the shard without touching the host;
+ *                i2s_allgather_boards(ctx, comm, d_boards, n_local, d_all, h_all) -- ncclAllGather on ctx's stream of
+ *                records_per_rank records per rank from d_boards (NULL = the shard: in place) into d_all (NULL = the
+ *                communicator's buffer); n_local <= records_per_rank of them are valid on this rank (the tail of the own
+ *                shard is zeroed); h_all, if not NULL, receives a host copy of all [world][records_per_rank] records.
+ *                Synchronous on return.  Rank r's records are those of images shard_range(total, r, world).
+ * librccl is opened with dlopen on first use; I2S_E_NO_DEVICE if it is missing. */
+#define I2S_COMM_ID_BYTES 128
+typedef struct i2s_comm i2s_comm;
+int  i2s_comm_unique_id(uint8_t id[I2S_COMM_ID_BYTES]);
+int  i2s_comm_create(i2s_comm** out, int device_id, const uint8_t id[I2S_COMM_ID_BYTES], int world, int rank,
+                     int records_per_rank);
+void i2s_comm_destroy(i2s_comm* comm);
+const char* i2s_comm_last_error(const i2s_comm* comm);
+i2s_board* i2s_comm_shard(i2s_comm* comm);
+i2s_board* i2s_comm_all(i2s_comm* comm);
+int  i2s_set_board_sink(i2s_ctx* ctx, i2s_board* d_sink);
+int  i2s_allgather_boards(i2s_ctx* ctx, i2s_comm* comm, const i2s_board* d_boards, int n_local,
+                          i2s_board* d_all, i2s_board* h_all);
+
+/* Per-kernel timing (bench.py's roofline objects): with profiling on, a detect call records one HIP event on the
+ * context's stream in front of every kernel group; i2s_last_kernel_timing returns the milliseconds each of the
+ * I2S_NSEG groups took, summed over the passes of the last detect call; i2s_kernel_timing_name(i) names group i. */
+#define I2S_NSEG 14
+int  i2s_set_profiling(i2s_ctx* ctx, int on);
+int  i2s_last_kernel_timing(const i2s_ctx* ctx, float ms[I2S_NSEG]);
+const char* i2s_kernel_timing_name(int i);
 
 /* Debug/test hooks (not part of the drop-in surface): Hough-circle accumulator of variant v
  * ((h)x(w) int32, cell layout = pixel layout) and line accumulators. Enabled by

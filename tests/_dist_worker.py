@@ -1,5 +1,7 @@
 """Worker of tests/test_dist_gloo.py: one rank of a 2-process gloo job.  Each rank detects its shard of a small
-synthetic batch (with the emulated build of the product sources, there is no GPU here) and all-gathers the boards."""
+synthetic batch and all-gathers the boards over gloo (host tensors).  argv[3] == "emu": the emulated build of the
+product sources (no GPU in the build container); "hip": the real library on GPU 0 -- both ranks share the one leased
+GPU, which is why this job cannot use RCCL (it refuses two ranks on one device)."""
 import os
 import sys
 
@@ -21,9 +23,10 @@ def main():
     dist.init_process_group("gloo")
     lo, hi = i2s_dist.shard_range(total, rank, world)
     imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(lo, hi)]
-    det = Detector(0, 2, 300, 260, lib=emu_util.emu_library())
+    lib = emu_util.emu_library() if sys.argv[3] == "emu" else None
+    det = Detector(0, 2, 300, 260, lib=lib)
     boards = det.detect_batch(imgs, full=False)
-    allb = i2s_dist.allgather_boards(boards, world)
+    allb = i2s_dist.allgather_boards_host(boards, total, rank, world)
     assert allb.shape == (total, 384)
     np.save(os.path.join(out, "rank%d.npy" % rank), allb)
     dist.barrier()
