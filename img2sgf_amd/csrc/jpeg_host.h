@@ -3,10 +3,12 @@
 // colour conversion: csrc/k_jpeg.h) runs on the device.  The reference reaches the same pixels through
 // PIL.Image.open(path).convert("RGB") (img2sgf.py:651), i.e. libjpeg-turbo with its defaults (JDCT_ISLOW, fancy upsampling);
 // this file and k_jpeg.h restate exactly that decoder for 8-bit Huffman JPEGs, sequential (SOF0 / SOF1) and progressive (SOF2,
-// spectral selection + successive approximation; a complete file needs no block smoothing, so the pixels are the inverse DCT
-// of the final coefficients), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, any scan script.  Everything else (arithmetic coding,
-// lossless, CMYK, RGB-coded, 12-bit) is reported as unsupported so that the caller can decode it elsewhere; nothing is
-// approximated.
+// spectral selection + successive approximation), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, any scan script that ends with
+// coefficients 0..9 of every component fully refined (Al = 0): Pillow leaves libjpeg's do_block_smoothing on, and
+// smoothing_ok() (jdcoefct.c) switches decompress_smooth_data on whenever one of those coefficients is not -- a DC-only
+// script, a final Al > 0, a file cut between scans; such files are reported as unsupported, like everything else that is not
+// restated here (arithmetic coding, lossless, CMYK, RGB-coded, 12-bit, a file that ends without EOI -- Pillow decides what a
+// truncated file means), so that the caller can decode it elsewhere; nothing is approximated.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -86,9 +88,14 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
     bool have_frame = false, adobe_rgb = false, latched[3] = {false, false, false};
     JpegHuff dc[4], ac[4];
     int dri = 0;
+    int cbits[3][10];                 // libjpeg's coef_bits for coefficients 0..9 (zigzag order): -1 = never sent, else the last Al
+    for (int c = 0; c < 3; c++) for (int k = 0; k < 10; k++) cbits[c][k] = -1;
     for (;;) {
-        if (p + 2 > n || d[p] != 0xFF) return f->scans.empty() ? JPG_BAD : JPG_OK;       // data ends without EOI: use what is there
-        while (p + 1 < n && d[p + 1] == 0xFF) p++;
+        // the data end without an EOI marker (or in the middle of one): what Pillow makes of such a file depends on where it
+        // was cut, so it is not decoded here
+        if (p + 2 > n || d[p] != 0xFF) return f->scans.empty() ? JPG_BAD : JPG_UNSUPPORTED;
+        while (p + 1 < n && d[p + 1] == 0xFF) p++;                   // fill bytes
+        if (p + 1 >= n) return f->scans.empty() ? JPG_BAD : JPG_UNSUPPORTED;
         const int m = d[p + 1];
         p += 2;
         if (m == 0xD9) break;
@@ -190,6 +197,8 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
                 const bool need_dc = sc.ss == 0 && sc.ah == 0, need_ac = sc.se > 0;
                 if ((need_dc && !dc[sc.td[k]].present) || (need_ac && !ac[sc.ta[k]].present)) return JPG_BAD;
             }
+            for (int k = 0; k < sc.ns; k++)
+                for (int z = sc.ss; z <= sc.se && z < 10; z++) cbits[sc.ci[k]][z] = sc.al;
             for (int t = 0; t < 4; t++) { sc.dc[t] = dc[t]; sc.ac[t] = ac[t]; }
             sc.dri = dri;
             // the entropy-coded segment runs up to the next marker that is neither a stuffed FF00 nor RSTn
@@ -210,6 +219,9 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
     }
     if (!have_frame || f->scans.empty()) return JPG_BAD;
     for (int c = 0; c < f->ncomp; c++) if (!latched[c]) return JPG_BAD;          // a component that no scan mentions
+    if (f->progressive)
+        for (int c = 0; c < f->ncomp; c++)
+            for (int k = 0; k < 10; k++) if (cbits[c][k] != 0) return JPG_UNSUPPORTED;   // libjpeg would smooth this image
     return JPG_OK;
 }
 

@@ -12,17 +12,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_HAS_GPU = None
+
+
 def _has_gpu():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
+    """Asked of the PRODUCT library (ctypes + HIP, no torch needed): can a context be created on device 0?  A box whose
+    torch is CPU-only or missing must not turn the parity suite into 150 silent skips."""
+    global _HAS_GPU
+    if _HAS_GPU is None:
+        try:
+            import ctypes as C
+            from img2sgf_amd import _lib
+            lib = _lib.load()
+            ctx = C.c_void_p()
+            ok = lib.dll.i2s_create(C.byref(ctx), 0, 1, 64, 64) == 0
+            if ok:
+                lib.dll.i2s_destroy(ctx)
+            _HAS_GPU = ok
+        except Exception:
+            _HAS_GPU = False
+    return _HAS_GPU
 
 
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
         return
+    if (config.getoption("markexpr") or "").strip() == "gpu":
+        raise pytest.UsageError("-m gpu was requested but libi2s_hip.so cannot create a context on device 0 "
+                                "(library missing, or no MI355X visible): nothing would run")
     skip = pytest.mark.skip(reason="no GPU in this container")
     for it in items:
         if "gpu" in it.keywords:
