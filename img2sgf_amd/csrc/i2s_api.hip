@@ -85,7 +85,7 @@ struct i2s_ctx {
 
 // segments of i2s_last_kernel_timing, in launch order
 static const char* const kSegName[I2S_NSEG] = {
-    "k_grey", "k_median3", "k_median57", "k_gauss357", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
+    "k_grey", "k_blur", "k_median57", "(unused)", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
     "k_sobel_nms_planes(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
     "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
 #define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
@@ -363,6 +363,24 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL(k_enhance, dim3(cdiv(wmax * 3, 1024), hmax, nb), dim3(256), 0, st, ctx->d_desc, ctx->d_lsum, fc, fb);
     }
 
+    // grey plane of every image: a single-channel source with dword-aligned rows IS its grey plane (cvtColor is the identity
+    // there, img2sgf.py:153 on a grey input), everything else gets its slot of the plane array filled by k_grey
+    bool need_grey = false;
+    for (int i = 0; i < nb; i++) {
+        ImgDesc& d = ctx->h_desc[i];
+        const bool alias = d.cn == 1 && ((uintptr_t)d.src & 3u) == 0 && (d.sstride & 3) == 0;
+        d.grey = alias ? d.src : plane_ptr(ctx, I2S_PLANE_GREY) + (size_t)i * g.slot;
+        d.gpitch = alias ? d.sstride : g.pitch;
+        need_grey |= !alias;
+    }
+    const int sum3 = t3.k[0] + t3.k[1] + t3.k[2], sum5 = t5.k[0] + t5.k[1] + t5.k[2] + t5.k[3] + t5.k[4];
+    const int sum7 = t7.k[0] + t7.k[1] + t7.k[2] + t7.k[3] + t7.k[4] + t7.k[5] + t7.k[6];
+    const bool float_blur = sum3 == 256 && sum5 == 256 && sum7 == 256;     // exactness condition of k_blur (see k_filters.h)
+    BlurTaps bt;
+    bt.c3 = (float)t3.k[1]; bt.a3 = (float)t3.k[0];
+    bt.c5 = (float)t5.k[2]; bt.a5 = (float)t5.k[1]; bt.b5 = (float)t5.k[0];
+    bt.c7 = (float)t7.k[3]; bt.a7 = (float)t7.k[2]; bt.b7 = (float)t7.k[1]; bt.d7 = (float)t7.k[0];
+
     for (;;) {
         I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
         I2S_HIP(hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx), st));
@@ -385,15 +403,21 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
         I2S_SEG(0);
-        hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
+        if (need_grey) hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
         I2S_SEG(1);
-        hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
+        if (float_blur) {
+            const int bgx = cdiv(wmax, 1024), bgy = cdiv(hmax, BL_R);      // 4 wavefronts x 256 pixels, BL_R rows
+            hipLaunchKernelGGL(k_blur, dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
+                               plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), bt, bgx, bgy);
+        } else {
+            hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
+            hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GAUSS3),
+                               plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
+        }
         I2S_SEG(2);
-        hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+        hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                            plane_ptr(ctx, I2S_PLANE_MEDIAN7), mx, my);
         I2S_SEG(3);
-        hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, grey, plane_ptr(ctx, I2S_PLANE_GAUSS3),
-                           plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
         const int ngx = cdiv(fx, NMS_TPB);                             // groups of NMS_TPB tiles along x
         // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
         // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
@@ -448,7 +472,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
         I2S_SEG(13);
 
-        hipLaunchKernelGGL(k_grid, dim3(nb), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, grey, gp, 1, ctx->d_res, ctx->d_boards);
+        hipLaunchKernelGGL(k_grid, dim3(nb), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, gp, 1, ctx->d_res, ctx->d_boards);
         I2S_HIP(hipEventRecord(ctx->ev[4], st));
         I2S_SEG(14);
 
@@ -556,7 +580,7 @@ extern "C" int i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* im
         for (int i = 0; i < nb; i++) {
             const int k = order[first + i];
             ImgDesc& d = ctx->h_desc[i];
-            d.cn = channels[k]; d.pad = 0;
+            d.cn = channels[k]; d.gpitch = 0; d.grey = nullptr;
             const bool enhance = p->contrast >= 0 || p->brightness >= 0;
             uint8_t* slot = ctx->d_src + (size_t)i * ctx->src_slot;
             if (xf) {
@@ -783,8 +807,8 @@ extern "C" int i2s_classify_batch(i2s_ctx* ctx, int first, int n, const i2s_para
     if (!ctx || !p || !boards || first < 0 || n < 1 || first + n > ctx->last_nb) return I2S_E_INVALID;
     I2S_HIP(hipSetDevice(ctx->device));
     const GridParams gp = grid_params(p);
-    hipLaunchKernelGGL(k_grid, dim3(n), dim3(GRID_THREADS), 0, ctx->stream, ctx->d_desc + first, ctx->geo,
-                       plane_ptr(ctx, I2S_PLANE_GREY) + (size_t)first * ctx->geo.slot, gp, 0, ctx->d_res + first, ctx->d_boards + first);
+    hipLaunchKernelGGL(k_grid, dim3(n), dim3(GRID_THREADS), 0, ctx->stream, ctx->d_desc + first, ctx->geo, gp, 0, ctx->d_res + first,
+                       ctx->d_boards + first);
     I2S_HIP(hipMemcpyAsync(boards, ctx->d_boards + first, n * sizeof(i2s_board), hipMemcpyDeviceToHost, ctx->stream));
     if (full) I2S_HIP(hipMemcpyAsync(full, ctx->d_res + first, n * sizeof(i2s_result), hipMemcpyDeviceToHost, ctx->stream));
     I2S_HIP(hipStreamSynchronize(ctx->stream));
@@ -811,12 +835,12 @@ extern "C" int i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int
     if (n_h) memcpy(hr->hlines, hlines, (size_t)n_h * sizeof(float));
     if (n_v) memcpy(hr->vlines, vlines, (size_t)n_v * sizeof(float));
     ImgDesc& d = ctx->h_desc[0];
-    d.src = nullptr; d.w = w; d.h = h; d.sstride = w; d.cn = 1; d.line_thr = hr->line_threshold; d.pad = 0;
+    d.src = nullptr; d.w = w; d.h = h; d.sstride = w; d.cn = 1; d.line_thr = hr->line_threshold;
+    d.gpitch = g.pitch; d.grey = plane_ptr(ctx, I2S_PLANE_GREY);
     hipError_t e1 = hipMemcpyAsync(ctx->d_desc, ctx->h_desc, sizeof(ImgDesc), hipMemcpyHostToDevice, st);
     hipError_t e2 = hipMemcpyAsync(ctx->d_res, hr, sizeof(i2s_result), hipMemcpyHostToDevice, st);
     hipError_t e3 = hipMemcpy2DAsync(plane_ptr(ctx, I2S_PLANE_GREY), g.pitch, grey, w, w, h, hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(k_grid, dim3(1), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GREY), grid_params(p), 1,
-                       ctx->d_res, ctx->d_boards);
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, grid_params(p), 1, ctx->d_res, ctx->d_boards);
     hipError_t e4 = hipMemcpyAsync(board, ctx->d_boards, sizeof(i2s_board), hipMemcpyDeviceToHost, st);
     hipError_t e5 = full ? hipMemcpyAsync(full, ctx->d_res, sizeof(i2s_result), hipMemcpyDeviceToHost, st) : hipSuccess;
     hipError_t e6 = hipStreamSynchronize(st);
@@ -825,6 +849,52 @@ extern "C" int i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int
     I2S_HIP(hipGetLastError());
     ctx->last_nb = 1;
     return I2S_OK;
+}
+
+// find_all_lines() (img2sgf.py:258-265) on an injected `circles_removed_image_np`: the three cv.HoughLines calls of
+// find_lines (:236-244) for both directions, nothing else.
+extern "C" int i2s_find_lines(i2s_ctx* ctx, const uint8_t* image, int w, int h, size_t stride, const i2s_params* p,
+                              float* hlines, int* n_h, float* vlines, int* n_v)
+{
+    if (!ctx || !image || !p || !hlines || !vlines || !n_h || !n_v || w < 1 || h < 1 || stride < (size_t)w) return I2S_E_INVALID;
+    if (w > ctx->max_w || h > ctx->max_h) return I2S_E_TOO_LARGE;
+    I2S_HIP(hipSetDevice(ctx->device));
+    Geo& g = ctx->geo;
+    g.nb = 1;
+    hipStream_t st = ctx->stream;
+    HoughTrig trig;
+    const int rc = hough_trig(p, &trig);
+    if (rc) return rc;
+    ctx->last_trig = trig;
+    i2s_result* hr = (i2s_result*)calloc(1, sizeof(i2s_result));
+    if (!hr) return I2S_E_INVALID;
+    ImgDesc& d = ctx->h_desc[0];
+    d.src = nullptr; d.w = w; d.h = h; d.sstride = w; d.cn = 1;
+    d.line_thr = hr->line_threshold = p->line_threshold > 0 ? p->line_threshold : i2s_choose_threshold(w, h);
+    d.gpitch = g.pitch; d.grey = plane_ptr(ctx, I2S_PLANE_GREY);
+    const int fx = cdiv(w, FT_W), fy = cdiv(h, FT_H);
+    hipError_t e[8];
+    e[0] = hipMemcpyAsync(ctx->d_desc, ctx->h_desc, sizeof(ImgDesc), hipMemcpyHostToDevice, st);
+    e[1] = hipMemcpyAsync(ctx->d_res, hr, sizeof(i2s_result), hipMemcpyHostToDevice, st);          // no circles: nothing is erased
+    e[2] = hipMemcpy2DAsync(plane_ptr(ctx, I2S_PLANE_EDGES), g.pitch, image, stride, w, h, hipMemcpyHostToDevice, st);
+    e[3] = hipMemsetAsync(ctx->d_lacc, 0, (size_t)LROWS * ctx->lrow * sizeof(int), st);
+    hipLaunchKernelGGL(k_erase_lines, dim3((unsigned)fx * fy), dim3(256), 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
+                       plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, fx, fy, ctx->d_tl_cnt, ctx->d_tl_idx);
+    hipLaunchKernelGGL(k_line_peaks, dim3(1), dim3(256), 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
+    e[4] = hipMemcpyAsync(hr, ctx->d_res, sizeof(i2s_result), hipMemcpyDeviceToHost, st);
+    e[5] = hipStreamSynchronize(st);
+    int out = I2S_OK;
+    for (int i = 0; i < 6 && out == I2S_OK; i++)
+        if (e[i] != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "i2s_find_lines: %s", hipGetErrorString(e[i])); out = I2S_E_HIP; }
+    if (out == I2S_OK && hr->status == I2S_ST_CAPACITY) out = I2S_E_UNSUPPORTED;                    // more than I2S_MAX_LINES peaks
+    if (out == I2S_OK) {
+        *n_h = hr->n_hlines; *n_v = hr->n_vlines;
+        memcpy(hlines, hr->hlines, (size_t)hr->n_hlines * sizeof(float));
+        memcpy(vlines, hr->vlines, (size_t)hr->n_vlines * sizeof(float));
+    }
+    free(hr);
+    ctx->last_nb = 1;
+    return out;
 }
 
 // Device -> host copy of `rows` rows of `rowb` bytes.  Dense on both sides: one linear copy.  Otherwise the whole pitched
@@ -853,6 +923,7 @@ extern "C" int i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* d
     if (!ctx || !dst || index < 0 || index >= ctx->last_nb || plane_id < 0 || plane_id >= NPLANES) return I2S_E_INVALID;
     const ImgDesc& d = ctx->h_desc[index];
     if (dst_stride < (size_t)d.w) return I2S_E_INVALID;
+    if (plane_id == I2S_PLANE_GREY) return fetch_rows(ctx, dst, dst_stride, d.grey, (size_t)d.gpitch, (size_t)d.w, (size_t)d.h);
     const uint8_t* src = plane_ptr(ctx, plane_id) + (size_t)index * ctx->geo.slot;
     return fetch_rows(ctx, dst, dst_stride, src, ctx->geo.pitch, (size_t)d.w, (size_t)d.h);
 }

@@ -29,7 +29,9 @@ struct ImgDesc {
     int sstride;          // bytes per source row
     int cn;               // 1 or 3
     int line_thr;         // Hough-lines threshold for this image
-    int pad;
+    int gpitch;           // bytes per row of the grey plane
+    const uint8_t* grey;  // grey plane (variant 0) of this image: its slot in the plane array, or -- for a single-channel source
+                          // whose rows are dword-aligned -- the source itself (cvtColor of a grey image is the identity)
 };
 
 // Plane addressing: plane p of image b starts at base + (p * nb + b) * slot; rows are `pitch` bytes.

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     const int y0 = tl.ty * CT_H;
     if (tl.tx * NMS_TPB * CT_W >= w || y0 >= h) return;
     const int tid = threadIdx.x;
-    const uint8_t* plane = planes + ((size_t)v * g.nb + b) * g.slot;
+    // variant 0 is the grey plane, which may be the source image itself (ImgDesc::grey)
+    const uint8_t* plane = v == 0 ? desc[b].grey : planes + ((size_t)v * g.nb + b) * g.slot;
+    const int ppitch = v == 0 ? desc[b].gpitch : g.pitch;
     // first output: the variant's map (modes 0, 2) or map 0 (mode 1); second output (mode 2 only): map 0
     const int m_first = main_mode == 1 ? 0 : 1 + v;
     uint8_t* mp = maps + ((size_t)m_first * g.nb + b) * g.slot;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     uint8_t* ep = main_out ? edges + (size_t)b * g.slot : nullptr;
     int* weak_first = main_mode == 1 ? weak_main : weak;
     TileRegs<SROWS, SWORDS, 256, BORDER_REPL> pre;
-    pre.fetch(plane, g.pitch, w, h, tl.tx * NMS_TPB * CT_W - 8, y0 - 2, tid);
+    pre.fetch(plane, ppitch, w, h, tl.tx * NMS_TPB * CT_W - 8, y0 - 2, tid);
     for (int tt = 0; tt < NMS_TPB; tt++) {
     const int tile_x = tl.tx * NMS_TPB + tt;
     const int x0 = tile_x * CT_W;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     if (tid == 0) { s_weak = 0; s_weak0 = 0; }
     pre.park<SSTR>(s_src, tid);
     __syncthreads();
-    if (tt + 1 < NMS_TPB && x0 + CT_W < w) pre.fetch(plane, g.pitch, w, h, x0 + CT_W - 8, y0 - 2, tid);
+    if (tt + 1 < NMS_TPB && x0 + CT_W < w) pre.fetch(plane, ppitch, w, h, x0 + CT_W - 8, y0 - 2, tid);
     // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry.
     // Two pixels per register (16-bit lanes, v_pk_* instructions): column sums / row differences of the 3x6
     // neighbourhood, then dx = col[+1] - col[-1], dy = dif[-1] + 2 dif[0] + dif[+1], mag = |dx| + |dy|.

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
     const TileId t = tile_of_block(gx, gy);
     const int b = t.z;
     const ImgDesc im = desc[b];
+    if (im.grey == im.src) return;                                   // the source is the grey plane (see ImgDesc)
     const int y = t.ty * 4 + threadIdx.y;
     const int x0 = (t.tx * 64 + threadIdx.x) * 4;
     if (y >= im.h || x0 >= im.w) return;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void gauss_on_tile(const unsigned* __restrict__ s_src
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
+__global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ desc, Geo g,
                                                   uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
                                                   Taps t3, Taps t5, Taps t7, int gx, int gy)
 {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ de
     const int x0 = t.tx * FT_W, y0 = t.ty * FT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
-    load_tile_words<GA_ROWS, GA_WORDS, GA_SSTR, 256, BORDER_R101>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - GA_R, tid);
+    load_tile_words<GA_ROWS, GA_WORDS, GA_SSTR, 256, BORDER_R101>(s_src, desc[b].grey, desc[b].gpitch, w, h, x0 - 4, y0 - GA_R, tid);
     __syncthreads();
     const size_t off = (size_t)b * g.slot;
     gauss_on_tile<3>(s_src, s_h, t3, out3 + off, g.pitch, w, h, x0, y0, tid);
@@ -127,16 +128,249 @@ __global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ de
     gauss_on_tile<7>(s_src, s_h, t7, out7 + off, g.pitch, w, h, x0, y0, tid);
 }
 
-// ---- K4: exact medians, BORDER_REPLICATE (cv.medianBlur, img2sgf.py:174).
+// ---- K3 + K4(3x3) fused: the three Gaussians AND the 3x3 median of the blur bank in one pass over the grey plane, in
+// registers -- no LDS, no barrier.  A lane owns one dword column (4 pixels) and walks down BL_R output rows; a wavefront
+// is 64 consecutive dwords = 256 pixels of a row, the left / right neighbour dwords come from the adjacent lanes (lanes 0
+// and 63 load theirs).  All arithmetic is FLOAT: measured on MI355X (profiles/r02_a_valu_rate_*.txt) v_add/mul/fma_f32 issue
+// at the full rate while every integer multiply, min/max, bit-field or packed instruction takes twice as long, and the
+// Gaussians are exact in f32: taps sum to 256 per axis, so every partial sum is an integer <= 255 * 256 * 256 < 2^24, and
+// (a + 32768) >> 16 = trunc(a * 2^-16 + 0.5) with both operations exact (the sum has at most 24 significant bits).
+//   horizontal: pair sums p[-k] + p[k] shared by the three kernels, then 2 / 3 / 4 multiply-adds;
+//   vertical:   the horizontal results of the last 7 rows live in a register ring (statically indexed: the row loop is
+//               unrolled by 7), same pairing;
+//   3x3 median: min3 / med3 / max3 of every column, then med3(max of minima, med of medians, min of maxima) (integers).
+// Borders (REFLECT_101 for the Gaussians, REPLICATE for the median) are byte permutations of the (left, mid, right)
+// dword triple with per-lane selectors computed once; only wavefronts that touch the left / right image edge execute them.
+// Top / bottom: the Gaussians read row reflect101(y); the median ring repeats the first / last image row.
+// Host side: used when every tap set sums to 256 (always for OpenCV's bit-exact kernels; the plain-rounding compatibility
+// mode can give 257, for which the integer kernels below remain).
+// three-operand min / med / max: one instruction each (the compiler forms v_med3 but leaves min3 / max3 as two instructions)
+#ifdef HIPEMU
 __device__ __forceinline__ int imin3(int a, int b, int c) { return imin(imin(a, b), c); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
 __device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }
+#else
+__device__ __forceinline__ int imin3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int imed3(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#endif
+constexpr int BL_R = 64;          // output rows per wavefront (+6 apron rows of horizontal work)
+struct BlurTaps { float c3, a3, c5, a5, b5, c7, a7, b7, d7; };   // centre, +-1, +-2, +-3 of the 3 / 5 / 7-tap kernels
+
+// Two things the compiler must not "improve" (both measured, profiles/r02_a_valu_rate_*.txt):
+//  * a multiply-add whose tap sits in a scalar register issues at HALF rate (v_fmac_f32 with an SGPR operand 4.4 cycles,
+//    with vector operands 2.9), and uniform kernel arguments land in SGPRs -- the taps are moved to vector registers once;
+//  * (float)a + (float)b of two bytes becomes an SDWA integer add + v_cvt_f32_u32 (two half-rate instructions per sum);
+//    converting every byte once with v_cvt_f32_ubyteN and adding floats (full rate) is cheaper.
+// The emulated build (tests/emu, HIPEMU) has no instruction set: there the plain C expressions stand in.
+#ifdef HIPEMU
+__device__ __forceinline__ float bl_vgpr(float x) { return x; }
+template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v) { return (float)((v >> (8 * BYTE)) & 0xffu); }
+#else
+__device__ __forceinline__ float bl_vgpr(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v)
+{
+    float r;
+    if (BYTE == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
+    else if (BYTE == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
+    else if (BYTE == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+#endif
+#define bl_f(v, byte) bl_fb<byte>(v)
+__device__ __forceinline__ unsigned bl_pack(float a, float b, float c, float d)
+{
+    return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24);
+}
+// (acc + 32768) >> 16 of the exact integer acc held in a float
+__device__ __forceinline__ float bl_round16(float acc, float k16) { return __builtin_fmaf(acc, k16, 0.5f); }   // bl_pack truncates
+
+// 3x3 medians of 4 adjacent pixels from three rows of 6 pixels (x0-1 .. x0+4), packed into one dword.  Integers: the
+// three-operand min / med / max instructions cost the same for floats and ints, and float min / max would first have to
+// canonicalise every input that crossed a basic block (IEEE mode), 18 more instructions per row.
+__device__ __forceinline__ unsigned bl_median_row(const int (&A)[6], const int (&B)[6], const int (&Cc)[6])
+{
+    int lo[6], mi[6], hi[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        lo[i] = imin3(A[i], B[i], Cc[i]);
+        mi[i] = imed3(A[i], B[i], Cc[i]);
+        hi[i] = imax3(A[i], B[i], Cc[i]);
+    }
+    unsigned o = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        o |= (unsigned)imed3(imax3(lo[q], lo[q + 1], lo[q + 2]), imed3(mi[q], mi[q + 1], mi[q + 2]), imin3(hi[q], hi[q + 1], hi[q + 2])) << (8 * q);
+    return o;
+}
+
+// the six median pixels x0-1 .. x0+4 (BORDER_REPLICATE) of a row from its raw dword triple
+__device__ __forceinline__ void bl_median_pixels(unsigned L, unsigned M, unsigned R, bool fix, const unsigned (&mS)[3], int (&F)[6])
+{
+    unsigned ml = L, mm = M, mr = R;
+    if (fix) { ml = __builtin_amdgcn_perm(M, L, mS[0]); mm = __builtin_amdgcn_perm(M, L, mS[1]); mr = __builtin_amdgcn_perm(R, M, mS[2]); }
+    F[0] = (int)(ml >> 24);
+    F[1] = (int)(mm & 0xffu); F[2] = (int)((mm >> 8) & 0xffu); F[3] = (int)((mm >> 16) & 0xffu); F[4] = (int)(mm >> 24);
+    F[5] = (int)(mr & 0xffu);
+}
+
+__global__ __launch_bounds__(256, 3) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
+                                                 uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
+                                                 BlurTaps tps, int gx, int gy)
+{
+    BlurTaps tp;
+    tp.c3 = bl_vgpr(tps.c3); tp.a3 = bl_vgpr(tps.a3);
+    tp.c5 = bl_vgpr(tps.c5); tp.a5 = bl_vgpr(tps.a5); tp.b5 = bl_vgpr(tps.b5);
+    tp.c7 = bl_vgpr(tps.c7); tp.a7 = bl_vgpr(tps.a7); tp.b7 = bl_vgpr(tps.b7); tp.d7 = bl_vgpr(tps.d7);
+    const float k16 = bl_vgpr(1.0f / 65536.0f);
+    // block = 4 wavefronts = 4 consecutive 256-pixel column groups of one band of BL_R rows
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z;
+    const ImgDesc im = desc[b];
+    const int w = im.w, h = im.h;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x0 = ((tl.tx * 4 + wave) * 64 + lane) * 4;
+    const int y0 = tl.ty * BL_R;
+    if (((tl.tx * 4 + wave) * 256) >= w || y0 >= h) return;          // whole wavefront outside the image
+    const bool active = x0 < w;
+    const uint8_t* src = im.grey;
+    const int sp = im.gpitch;
+    const size_t obase = (size_t)b * g.slot;
+
+    // per-lane border selectors: byte k of the (L, M, R) triple is pixel x0 - 4 + k
+    const bool fix_lane = active && (x0 - 3 < 0 || x0 + 6 >= w);
+    const bool fix = __any(fix_lane ? 1 : 0) != 0;
+    unsigned gA[3] = {0x03020100u, 0x07060504u, 0x0c0c0c0cu}, gB[3] = {0x03020100u, 0x03020100u, 0x07060504u};
+    unsigned mS[3] = {0x03020100u, 0x07060504u, 0x07060504u};
+    if (fix_lane) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            unsigned a = 0, bsel = 0, m = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int p = x0 - 4 + 4 * d + j;
+                int sg = reflect101(p, w) - (x0 - 4), sm = iclamp(p, 0, w - 1) - (x0 - 4);
+                if (sg < 0 || sg > 11) sg = 4;                        // a pixel no valid output of this lane needs
+                if (sm < 0 || sm > 11) sm = 4;
+                a |= (unsigned)(sg < 8 ? sg : 0x0c) << (8 * j);
+                bsel |= (unsigned)(sg < 8 ? j : sg - 4) << (8 * j);
+                // median: sources of L' and M' lie in (L, M), sources of R' in (M, R)
+                const int ms = d < 2 ? sm : sm - 4;
+                m |= (unsigned)(ms < 0 || ms > 7 ? 4 : ms) << (8 * j);
+            }
+            gA[d] = a; gB[d] = bsel; mS[d] = m;
+        }
+    }
+
+    // one dword of a row for this lane, plus the edge dword of lanes 0 / 63 (their outer neighbour)
+    const bool has_e = (lane == 0 && x0 >= 4) || (lane == 63 && x0 + 4 < w);
+    const int xe = lane == 0 ? x0 - 4 : x0 + 4;
+
+    float H3[7][4], H5[7][4], H7[7][4];        // horizontal results of the last 7 input rows, slot = row index mod 7
+    int F1[6], F2[6];                           // median ring: pixels x0-1 .. x0+4 of the two previous rows
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) { H3[i][q] = 0.f; H5[i][q] = 0.f; H7[i][q] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { F1[i] = 0; F2[i] = 0; }
+    if (y0 == 0) {
+        // BORDER_REPLICATE above the image: the ring starts out holding row 0 as "row -1"
+        unsigned M = 0, E = 0;
+        if (active) M = *reinterpret_cast<const unsigned*>(src + x0);
+        if (has_e) E = *reinterpret_cast<const unsigned*>(src + xe);
+        const unsigned up = (unsigned)__shfl_up((int)M, 1), dn = (unsigned)__shfl_down((int)M, 1);
+        bl_median_pixels(lane == 0 ? E : up, M, lane == 63 ? E : dn, fix, mS, F1);
+    }
+
+    unsigned nM = 0, nE = 0;
+    {
+        const uint8_t* rp = src + rowoff(reflect101(y0 - 3, h), sp);
+        if (active) nM = *reinterpret_cast<const unsigned*>(rp + x0);
+        if (has_e) nE = *reinterpret_cast<const unsigned*>(rp + xe);
+    }
+    static_assert((BL_R + 6) % 7 == 0, "the row loop is unrolled by the ring depth");
+    const int t_end = imin(BL_R + 6, h + 3 - (y0 - 3));               // input rows beyond h + 2 feed no output of this band
+    for (int t0 = 0; t0 < t_end; t0 += 7) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int t = t0 + u;
+            const int yi = y0 - 3 + t;
+            const unsigned M = nM, E = nE;
+            {                                                          // next row's loads are in flight while this one is computed
+                const uint8_t* rp = src + rowoff(reflect101(yi + 1, h), sp);
+                if (active) nM = *reinterpret_cast<const unsigned*>(rp + x0);
+                if (has_e) nE = *reinterpret_cast<const unsigned*>(rp + xe);
+            }
+            const unsigned up = (unsigned)__shfl_up((int)M, 1), dn = (unsigned)__shfl_down((int)M, 1);
+            const unsigned L = lane == 0 ? E : up, R = lane == 63 ? E : dn;
+            unsigned gl = L, gm = M, gr = R;
+            if (fix) {
+                gl = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[0]), gB[0]);
+                gm = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[1]), gB[1]);
+                gr = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[2]), gB[2]);
+            }
+            float f[10];                                              // pixels x0 - 3 .. x0 + 6
+            f[0] = bl_f(gl, 1); f[1] = bl_f(gl, 2); f[2] = bl_f(gl, 3);
+            f[3] = bl_f(gm, 0); f[4] = bl_f(gm, 1); f[5] = bl_f(gm, 2); f[6] = bl_f(gm, 3);
+            f[7] = bl_f(gr, 0); f[8] = bl_f(gr, 1); f[9] = bl_f(gr, 2);
+            // horizontal pass of the three Gaussians into ring slot u
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float c = f[q + 3];
+                const float s1 = f[q + 2] + f[q + 4], s2 = f[q + 1] + f[q + 5], s3 = f[q] + f[q + 6];
+                H3[u][q] = __builtin_fmaf(tp.a3, s1, tp.c3 * c);
+                H5[u][q] = __builtin_fmaf(tp.b5, s2, __builtin_fmaf(tp.a5, s1, tp.c5 * c));
+                H7[u][q] = __builtin_fmaf(tp.d7, s3, __builtin_fmaf(tp.b7, s2, __builtin_fmaf(tp.a7, s1, tp.c7 * c)));
+            }
+            // 3x3 median: image row yi completes output row yi - 1 (rows yi - 2, yi - 1, yi = F2, F1, F0); the last image
+            // row also completes itself (BORDER_REPLICATE below the image: rows h - 2, h - 1, h - 1)
+            if (yi >= 0 && yi < h) {
+                int F0[6];
+                bl_median_pixels(L, M, R, fix, mS, F0);
+                const int ym = yi - 1;
+                if (ym >= y0 && ym < y0 + BL_R) {
+                    const unsigned o = bl_median_row(F2, F1, F0);
+                    if (active) *reinterpret_cast<unsigned*>(med3 + obase + rowoff(ym, g.pitch) + x0) = o;
+                }
+                if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) {
+                    const unsigned o = bl_median_row(F1, F0, F0);
+                    if (active) *reinterpret_cast<unsigned*>(med3 + obase + rowoff(yi, g.pitch) + x0) = o;
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) { F2[i] = F1[i]; F1[i] = F0[i]; }
+            }
+            // vertical pass: output row yo = yi - 3 from ring slots t-6 .. t (centre t-3)
+            const int yo = yi - 3;
+            if (t >= 6 && yo < h && active) {
+                constexpr int NS = 7;
+                const int c = (u + 4) % NS, p1 = (u + 5) % NS, m1 = (u + 3) % NS, p2 = (u + 6) % NS, m2 = (u + 2) % NS, p3 = u, m3 = (u + 1) % NS;
+                float r3[4], r5[4], r7[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    r3[q] = bl_round16(__builtin_fmaf(tp.a3, H3[p1][q] + H3[m1][q], tp.c3 * H3[c][q]), k16);
+                    r5[q] = bl_round16(__builtin_fmaf(tp.b5, H5[p2][q] + H5[m2][q],
+                                                      __builtin_fmaf(tp.a5, H5[p1][q] + H5[m1][q], tp.c5 * H5[c][q])), k16);
+                    r7[q] = bl_round16(__builtin_fmaf(tp.d7, H7[p3][q] + H7[m3][q],
+                                                      __builtin_fmaf(tp.b7, H7[p2][q] + H7[m2][q],
+                                                                     __builtin_fmaf(tp.a7, H7[p1][q] + H7[m1][q], tp.c7 * H7[c][q]))), k16);
+                }
+                const int off = rowoff(yo, g.pitch) + x0;
+                *reinterpret_cast<unsigned*>(out3 + obase + off) = bl_pack(r3[0], r3[1], r3[2], r3[3]);
+                *reinterpret_cast<unsigned*>(out5 + obase + off) = bl_pack(r5[0], r5[1], r5[2], r5[3]);
+                *reinterpret_cast<unsigned*>(out7 + obase + off) = bl_pack(r7[0], r7[1], r7[2], r7[3]);
+            }
+        }
+    }
+}
+
+// ---- K4: exact medians, BORDER_REPLICATE (cv.medianBlur, img2sgf.py:174).
 
 // 3x3: sort the three values of every column once (min3 / med3 / max3, shared by the three windows that contain the
 // column), then median = med3( max of the column minima, med of the column medians, min of the column maxima ).
 // 4 pixels per thread, dword LDS traffic.
-__global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ desc, Geo g,
-                                                 const uint8_t* __restrict__ grey, uint8_t* __restrict__ out, int gx, int gy)
+__global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ out, int gx, int gy)
 {
     constexpr int SROWS = FT_H + 2, SWORDS = FT_W / 4 + 2, SSTR = SWORDS + 1;
     constexpr int NS = FT_W / 4;
@@ -147,7 +381,7 @@ __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ des
     const int x0 = t.tx * FT_W, y0 = t.ty * FT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
-    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - 1, tid);
+    load_tile_words<SROWS, SWORDS, SSTR, 256, BORDER_REPL>(s_src, desc[b].grey, desc[b].gpitch, w, h, x0 - 4, y0 - 1, tid);
     __syncthreads();
     uint8_t* o = out + (size_t)b * g.slot;
     for (int i = tid; i < FT_H * NS; i += 256) {
@@ -215,7 +449,7 @@ __device__ __forceinline__ unsigned median_planes(const unsigned (&plo)[8], cons
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
+__global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
                                                   uint8_t* __restrict__ out5, uint8_t* __restrict__ out7, int gx, int gy)
 {
     __shared__ unsigned s_src[M_ROWS * M_SSTR];
@@ -226,7 +460,7 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
     const int x0 = tl.tx * MT_W, y0 = tl.ty * MT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
-    load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, grey + (size_t)b * g.slot, g.pitch, w, h, x0 - 4, y0 - 3, tid);
+    load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, desc[b].grey, desc[b].gpitch, w, h, x0 - 4, y0 - 3, tid);
     __syncthreads();
     {
         // 8 pixels -> 8 plane bytes (8x8 bit-matrix transpose: output byte p = plane p, bit i = pixel i)

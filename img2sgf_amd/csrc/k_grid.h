@@ -119,7 +119,7 @@ __device__ __forceinline__ void cluster_axis(const float* __restrict__ rho, int 
 // grid (nb), block GRID_THREADS.  grey = variant plane 0.  Reads res[b].{circles, n_circles, hlines, vlines, status}
 // and fills the rest of res[b] and boards[b].  do_cluster = 0 re-runs only identify_board on the stored grid
 // (apply_black_thresh, img2sgf.py:762-766).
-__global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ grey,
+__global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc, Geo g,
                                               GridParams gp, int do_cluster, i2s_result* __restrict__ res,
                                               i2s_board* __restrict__ boards)
 {
@@ -257,7 +257,9 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
     const int ns = s_i[2];
     {
         const int wave = tid >> 6, lane = tid & 63;
-        const uint8_t* gp0 = grey + (size_t)b * g.slot;
+        const uint8_t* gp0 = desc[b].grey;                               // may be the source image itself (ImgDesc::grey)
+        const int gpitch = desc[b].gpitch;
+        const uint8_t* gend = gp0 + rowoff(desc[b].h - 1, gpitch) + desc[b].w;      // one past the last pixel
         for (int s0 = 0; s0 < ns; s0 += GRID_THREADS / 64) {
             const int s = s0 + wave;
             unsigned sum = 0;
@@ -274,11 +276,15 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
                 const int ry = lane / imax(L, 1), lx = lane - ry * L;
                 if (bw > 0 && ry < rows_per)
                     for (int yy = ry; yy < bh; yy += rows_per) {
-                        const uint8_t* row = gp0 + rowoff(ymin + yy, g.pitch) + xmin;
+                        const uint8_t* row = gp0 + rowoff(ymin + yy, gpitch) + xmin;
                         for (int xx = 4 * lx; xx < bw; xx += 4 * L) {
                             unsigned v4;
-                            __builtin_memcpy(&v4, row + xx, 4);
                             const int nvalid = bw - xx;                       // >= 1
+                            if (row + xx + 4 <= gend) __builtin_memcpy(&v4, row + xx, 4);
+                            else {                                            // the last pixels of an image used in place
+                                v4 = 0;
+                                for (int q = 0; q < 4 && q < nvalid; q++) v4 |= (unsigned)row[xx + q] << (8 * q);
+                            }
                             if (nvalid < 4) v4 &= (1u << (8 * nvalid)) - 1u;
                             sum = __builtin_amdgcn_sad_u8(v4, 0u, sum);
                         }

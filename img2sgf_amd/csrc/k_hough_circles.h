@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
     const size_t off = ((size_t)v * g.nb + b) * g.slot;
-    const uint8_t* plane = planes + off;
+    const uint8_t* plane = v == 0 ? desc[b].grey : planes + off;      // variant 0 may be the source image itself (ImgDesc::grey)
+    const int ppitch = v == 0 ? desc[b].gpitch : g.pitch;
     const uint8_t* map = maps + off;
     const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)tl.ty * EBB_Y * g.bw + (size_t)tl.tx * EBB_X;
     if (tid < EBB_X * EBB_Y) s_n[tid] = 0;
@@ -100,20 +101,22 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
         const int lx = le & 127, lyy = le >> 7;
         const int x = x0 + lx, y = y0 + lyy;
         int dx, dy;
-        if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2) {
-            // interior pixel: the 3x3 neighbourhood as three (unaligned) dword loads instead of eight byte loads
-            const uint8_t* pc = plane + rowoff(y, g.pitch) + (x - 1);
+        if (x >= 1 && y >= 1 && y <= h - 2 && (x <= w - 3 || (x == w - 2 && y <= h - 3))) {
+            // interior pixel: the 3x3 neighbourhood as three (unaligned) dword loads instead of eight byte loads.  The
+            // fourth byte of a load is pixel x + 2 (unused): for x = w - 2 it is the first byte of the next row, which
+            // does not exist below the last row of a source image used in place -- that one pixel takes the byte path.
+            const uint8_t* pc = plane + rowoff(y, ppitch) + (x - 1);
             unsigned r0, r1, r2;
-            __builtin_memcpy(&r0, pc - g.pitch, 4);
+            __builtin_memcpy(&r0, pc - ppitch, 4);
             __builtin_memcpy(&r1, pc, 4);
-            __builtin_memcpy(&r2, pc + g.pitch, 4);
+            __builtin_memcpy(&r2, pc + ppitch, 4);
             const int a = (int)(r0 & 0xffu), bb = (int)((r0 >> 8) & 0xffu), c = (int)((r0 >> 16) & 0xffu);
             const int d = (int)(r1 & 0xffu), f = (int)((r1 >> 16) & 0xffu);
             const int gg = (int)(r2 & 0xffu), hh = (int)((r2 >> 8) & 0xffu), ii = (int)((r2 >> 16) & 0xffu);
             dx = (c + 2 * f + ii) - (a + 2 * d + gg);
             dy = (gg + 2 * hh + ii) - (a + 2 * bb + c);
         } else {
-            sobel_at(plane, g.pitch, w, h, x, y, dx, dy);
+            sobel_at(plane, ppitch, w, h, x, y, dx, dy);
         }
         if (dx == 0 && dy == 0) continue;
         const float vx = (float)dx, vy = (float)dy;

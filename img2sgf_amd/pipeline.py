@@ -294,6 +294,23 @@ class Detector:
         self._last_shapes = [grey.shape]
         return _detection_from_result(res)
 
+    def find_all_lines(self, circles_removed, params: Optional[Params] = None):
+        """find_all_lines() (img2sgf.py:258-265): (hlines, vlines) float32 rho lists of an injected circles_removed image."""
+        params = params or Params()
+        img = np.ascontiguousarray(circles_removed, np.uint8)
+        if img.ndim != 2:
+            raise ValueError("circles_removed must be HxW uint8")
+        hl = np.zeros(_lib.MAX_LINES, np.float32)
+        vl = np.zeros(_lib.MAX_LINES, np.float32)
+        nh, nv = C.c_int(0), C.c_int(0)
+        f32p = C.POINTER(C.c_float)
+        p = params.to_c()
+        self._check(self.lib.dll.i2s_find_lines(self._ctx, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[0],
+                                                img.strides[0], C.byref(p), hl.ctypes.data_as(f32p), C.byref(nh),
+                                                vl.ctypes.data_as(f32p), C.byref(nv)))
+        self._last_shapes = [img.shape]
+        return hl[:nh.value].copy(), vl[:nv.value].copy()
+
     def fetch_plane(self, index, plane):
         """numpy image of a device plane of the last pass: 'grey', 'edges', 'removed', 'median3', ... or an int id."""
         pid = PLANE_NAMES[plane] if isinstance(plane, str) else int(plane)
@@ -485,6 +502,65 @@ def find_grid(grey, circles, hlines, vlines, params: Optional[Params] = None, de
     """img2sgf.py:546-576 with find_lines' outputs injected."""
     d = _detector_for([grey], detector)
     return d.grid_from_lines(grey, circles, hlines, vlines, params)
+
+
+# Direction, img2sgf.py:74-80
+HORIZONTAL, VERTICAL = 1, 2
+
+
+def find_all_lines(circles_removed_image_np, threshold, params: Optional[Params] = None, detector: Optional[Detector] = None):
+    """img2sgf.py:258-265: (hlines, vlines) as (n,1) float32 rho columns ([] when a direction has no line), the three
+    cv.HoughLines calls of find_lines on the device."""
+    import dataclasses
+    d = _detector_for([circles_removed_image_np], detector)
+    p = dataclasses.replace(params or Params(), line_threshold=int(threshold))
+    hl, vl = d.find_all_lines(circles_removed_image_np, p)
+    col = lambda a: a.reshape(-1, 1) if len(a) else []
+    return col(hl), col(vl)
+
+
+def find_lines(circles_removed_image_np, threshold, direction, params: Optional[Params] = None,
+               detector: Optional[Detector] = None):
+    """img2sgf.py:230-255 for one Direction (HORIZONTAL / VERTICAL): the (n,1) rho column, or []."""
+    hl, vl = find_all_lines(circles_removed_image_np, threshold, params, detector)
+    return hl if direction in (HORIZONTAL, "H", "HORIZONTAL") else vl
+
+
+_DUMMY_GREY = np.zeros((16, 16), np.uint8)
+
+
+def cluster_lines(hlines, vlines, params: Optional[Params] = None, detector: Optional[Detector] = None):
+    """img2sgf.py:295-332 without the plotting: (hcentres, vcentres, found_grid) -- single-linkage clusters of the rho
+    lists at distance_threshold = min_grid_spacing (find_clusters_fixed_threshold :268-280), centre = float32 mean
+    (get_cluster_centres :283-292); found_grid = both non-empty (:329-330).  Runs on the device (i2s_grid_from_lines)."""
+    d = _detector_for([_DUMMY_GREY], detector)
+    det = d.grid_from_lines(_DUMMY_GREY, np.zeros((0, 3), np.float32), hlines, vlines, params)
+    return det.hcentres, det.vcentres, det.found_grid
+
+
+def validate_grid(hcentres, vcentres, circles, params: Optional[Params] = None, detector: Optional[Detector] = None):
+    """img2sgf.py:420-445 on explicit cluster centres: (valid, newcircles, vsize, hsize, hcentres_complete,
+    vcentres_complete, hspace, vspace), or (False, circles, 0, 0, None, None, None, None).  Runs on the device: every
+    centre is handed to i2s_grid_from_lines as a pair of identical rho values (a two-member cluster whose float32 mean is the
+    centre), which requires what cluster_lines guarantees -- centres of one direction at least min_grid_spacing apart and
+    representable in float32."""
+    p = params or Params()
+    c = np.ascontiguousarray(circles, np.float32).reshape(-1, 3)
+
+    def doubled(x):
+        x = np.asarray(x, np.float64).reshape(-1)
+        x32 = x.astype(np.float32)
+        if not np.array_equal(x32.astype(np.float64), x):
+            raise ValueError("cluster centres must be float32 values (they are float32 means in the reference)")
+        if len(x) > 1 and np.diff(np.sort(x)).min() < p.min_grid_spacing:
+            raise ValueError("cluster centres closer than min_grid_spacing cannot come from cluster_lines")
+        return np.repeat(x32, 2)
+
+    d = _detector_for([_DUMMY_GREY], detector)
+    det = d.grid_from_lines(_DUMMY_GREY, c, doubled(hcentres), doubled(vcentres), p)
+    if not det.valid_grid:
+        return (False, c if len(c) else [], 0, 0, None, None, None, None)
+    return (True, det.circles, det.vsize, det.hsize, det.hcentres_complete, det.vcentres_complete, det.hspace, det.vspace)
 
 
 def to_SGF(board, side_to_move):

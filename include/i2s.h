@@ -15,6 +15,7 @@
  *                         (re-classify cached detections with a new black threshold / alignment).
  *   i2s_grid_from_lines   find_grid() 546-576 with injected circles and Hough-line rho lists
  *                         (what find_grid sees after find_lines 230-255 returned).
+ *   i2s_find_lines        find_all_lines() 258-265 / find_lines() 230-255 on an injected circles_removed image.
  *   i2s_choose_threshold  choose_threshold() 606-613.
  *   i2s_detect_batch_xf   the same, preceded on the device by crop_and_rotate_image() 110-114
  *                         (PIL Image.rotate(NEAREST, fillcolor white, center) + Image.crop).
@@ -223,6 +224,13 @@ int  i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int h,
                          const float* circles, int n_circles,
                          const float* hlines, int n_h, const float* vlines, int n_v,
                          const i2s_params* p, i2s_board* board, i2s_result* full);
+
+/* find_all_lines() (img2sgf.py:258-265) alone: the three cv.HoughLines calls of find_lines (:236-244) for both directions
+ * on an injected `circles_removed_image_np` (host, h rows of w bytes, `stride` bytes apart; any non-zero byte votes).
+ * hlines / vlines: caller buffers of I2S_MAX_LINES floats, rho in find_lines' output order.  I2S_E_UNSUPPORTED if more
+ * than I2S_MAX_LINES peaks exist in a direction. */
+int  i2s_find_lines(i2s_ctx* ctx, const uint8_t* image, int w, int h, size_t stride, const i2s_params* p,
+                    float* hlines, int* n_h, float* vlines, int* n_v);
 
 /* Copy one plane of image `index` of the last pass to host memory (dst: h rows of w bytes). */
 int  i2s_fetch_plane(i2s_ctx* ctx, int index, int plane_id, uint8_t* dst, size_t dst_stride);

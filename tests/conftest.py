@@ -22,6 +22,13 @@ def _has_gpu():
     if _HAS_GPU is None:
         try:
             import ctypes as C
+            try:
+                # tests that hand torch tensors to the library need torch's own bundled HIP runtime to be the one in the
+                # process: load it BEFORE libi2s_hip.so pulls in /opt/rocm's (the other order leaves torch without GPUs)
+                import torch
+                torch.cuda.is_available()
+            except Exception:
+                pass
             from img2sgf_amd import _lib
             lib = _lib.load()
             ctx = C.c_void_p()

@@ -97,6 +97,9 @@ template <class T> static inline T __shfl(T v, int src)
     return out;
 }
 template <class T> static inline T __shfl_down(T v, unsigned d) { return __shfl(v, hipemu::cur->lane + (int)d < 64 ? hipemu::cur->lane + (int)d : hipemu::cur->lane); }
+template <class T> static inline T __shfl_up(T v, unsigned d) { return __shfl(v, hipemu::cur->lane - (int)d >= 0 ? hipemu::cur->lane - (int)d : hipemu::cur->lane); }
+static inline int __any(int pred) { return __ballot(pred) != 0ull; }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 template <class T> static inline T __shfl_xor(T v, int m) { return __shfl(v, hipemu::cur->lane ^ m); }
 // wave-uniform lane select (v_readlane_b32): all live lanes call it with the same lane index
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }

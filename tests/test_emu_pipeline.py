@@ -229,3 +229,29 @@ def test_jpeg_decode_matches_pillow(lib):
     with pytest.raises(I2sError):
         det.detect_jpeg([buf.getvalue()], Params(), full=False)
     det.close()
+
+
+def test_blur_bank_shapes_emulated(lib):
+    """k_blur's border machinery (byte permutations of the lane's dword triple, reflect / replicate rows, the 7-row ring)
+    and the bit-plane medians on awkward shapes -- the emulated twin of tests/test_gpu_parity.py::test_blur_bank_shapes."""
+    from oracle import cv_oracle as cvo
+    rng = np.random.default_rng(78)
+    shapes = [(1, 1), (2, 3), (3, 2), (5, 7), (9, 4), (7, 8), (8, 13), (66, 12), (13, 257), (70, 260)]
+    det = Detector(0, 2, 260, 70, lib=lib)
+    for k in range(0, len(shapes), 2):
+        imgs = []
+        for n, (h, w) in enumerate(shapes[k:k + 2]):
+            im = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            if (k + n) % 3 == 0:
+                im = np.where(im < 128, 0, 255).astype(np.uint8)
+            imgs.append(im)
+        det.detect_batch(imgs, full=False)
+        for i, im in enumerate(imgs):
+            for name, kk in (("gauss3", 3), ("gauss5", 5), ("gauss7", 7)):
+                np.testing.assert_array_equal(det.fetch_plane(i, name), cvo.gaussian_blur(im, kk, kk), err_msg="%s %s" % (name, im.shape))
+            for name, kk in (("median3", 3), ("median5", 5), ("median7", 7)):
+                np.testing.assert_array_equal(det.fetch_plane(i, name), cvo.median_blur(im, kk), err_msg="%s %s" % (name, im.shape))
+            np.testing.assert_array_equal(det.fetch_plane(i, "grey"), im)
+    det.detect_batch([np.full((20, 40), 255, np.uint8)], Params(gauss_kernel_mode=1), full=False)     # tap sums != 256: integer kernels
+    np.testing.assert_array_equal(det.fetch_plane(0, "gauss7"), cvo.gaussian_blur(np.full((20, 40), 255, np.uint8), 7, 7, 1))
+    det.close()

@@ -10,6 +10,7 @@ import parity
 from helpers import GOLDEN, load_glue_golden, synth_grey
 from img2sgf_amd import synth
 from img2sgf_amd.pipeline import Detector, Params, board_to_sgf
+from oracle import cv_oracle as cvo
 from oracle import pipeline as opipe
 
 pytestmark = pytest.mark.gpu
@@ -322,4 +323,69 @@ def test_large_images():
     col = np.ascontiguousarray(np.stack([sub, sub[:, ::-1], sub], axis=-1))
     det = Detector(0, 3, 2560, 2048)
     parity.run_and_compare(det, [big, wide, col])
+    det.close()
+
+
+def _blur_planes_match(det, imgs):
+    det.detect_batch(imgs, full=False)
+    for i, im in enumerate(imgs):
+        grey = cvo.bgr2gray(im)
+        want = {"grey": grey, "median3": cvo.median_blur(grey, 3), "median5": cvo.median_blur(grey, 5),
+                "median7": cvo.median_blur(grey, 7), "gauss3": cvo.gaussian_blur(grey, 3, 3),
+                "gauss5": cvo.gaussian_blur(grey, 5, 5), "gauss7": cvo.gaussian_blur(grey, 7, 7)}
+        for name, w_ in want.items():
+            got = det.fetch_plane(i, name)
+            bad = np.argwhere(got != w_)
+            assert len(bad) == 0, "%s of image %d %s differs at %d px, first %s got %d want %d" % (
+                name, i, im.shape, len(bad), bad[0], got[tuple(bad[0])], w_[tuple(bad[0])])
+
+
+def test_blur_bank_shapes():
+    """The fused register-resident blur kernel (k_blur: 3 Gaussians + 3x3 median, borders as byte permutations of the lane's
+    dword triple) and the bit-plane medians on every awkward shape: widths around the 4-pixel lane, the 256-pixel wavefront
+    and the 1024-pixel workgroup, heights around the 7-row ring and the 64-row band, grey sources used in place (dword-aligned
+    rows) and staged copies (odd widths), colour sources."""
+    rng = np.random.default_rng(77)
+    shapes = [(1, 1), (1, 2), (2, 1), (3, 3), (1, 9), (9, 1), (4, 4), (5, 7), (6, 8), (7, 13), (8, 8), (9, 12), (63, 255),
+              (64, 256), (65, 257), (66, 260), (70, 1023), (71, 1024), (129, 1025), (130, 1028), (5, 1280), (200, 252), (127, 4)]
+    det = Detector(0, 4, 1280, 200)
+    for k in range(0, len(shapes), 4):
+        imgs = []
+        for (h, w) in shapes[k:k + 4]:
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                imgs.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+            elif kind == 1:
+                imgs.append(np.where(rng.random((h, w)) < 0.5, 0, 255).astype(np.uint8))      # extremes: 255 * 256 * 256 sums
+            else:
+                imgs.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        _blur_planes_match(det, imgs)
+    det.close()
+    # saturated planes (the largest partial sums of the float Gaussians) and device-resident sources used in place
+    import torch
+    det = Detector(0, 2, 1024, 200)
+    for val in (255, 254, 1):
+        _blur_planes_match(det, [np.full((100, 1000), val, np.uint8)])
+    t = torch.from_numpy(rng.integers(0, 256, (2, 200, 1024), dtype=np.uint8)).cuda()
+    det.detect_device(t)
+    for i in range(2):
+        grey = t[i].cpu().numpy()
+        for name, k in (("gauss3", 3), ("gauss5", 5), ("gauss7", 7)):
+            np.testing.assert_array_equal(det.fetch_plane(i, name), cvo.gaussian_blur(grey, k, k))
+        for name, k in (("median3", 3), ("median5", 5), ("median7", 7)):
+            np.testing.assert_array_equal(det.fetch_plane(i, name), cvo.median_blur(grey, k))
+        np.testing.assert_array_equal(det.fetch_plane(i, "grey"), grey)
+    det.close()
+
+
+def test_plain_rounding_gaussian_taps_use_the_integer_kernels():
+    """gauss_kernel_mode = 1 can give tap sums of 257, outside the float kernel's exactness condition: the
+    integer kernels take over and still match the oracle."""
+    rng = np.random.default_rng(3)
+    img = np.where(rng.random((90, 130)) < 0.3, 255, rng.integers(0, 256, (90, 130))).astype(np.uint8)
+    det = Detector(0, 1, 130, 90)
+    det.detect_batch([img], Params(gauss_kernel_mode=1), full=False)
+    for name, k in (("gauss3", 3), ("gauss5", 5), ("gauss7", 7)):
+        np.testing.assert_array_equal(det.fetch_plane(0, name), cvo.gaussian_blur(img, k, k, 1))
+    np.testing.assert_array_equal(det.fetch_plane(0, "median3"), cvo.median_blur(img, 3))
     det.close()

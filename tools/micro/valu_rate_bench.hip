@@ -146,6 +146,25 @@
 #define I_ADD_DPP_SHR(d) "v_add_u32_dpp " d ", " d ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
 #define I_MOV_DPP_BCAST(d) "v_mov_b32_dpp " d ", %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
 #define I_ADD_U32_S(d) "v_add_u32 " d ", %10, " d "\n"
+#define I_FMAC_F32_S(d) "v_fmac_f32 " d ", %10, %9\n"
+#define I_FMA_F32_S(d) "v_fma_f32 " d ", " d ", %10, %9\n"
+#define I_MUL_F32_S(d) "v_mul_f32 " d ", %10, " d "\n"
+#define I_AND_S(d) "v_and_b32 " d ", %10, " d "\n"
+#define I_AND_LIT(d) "v_and_b32 " d ", 0x7f7f7f7f, " d "\n"
+#define I_ADD_LIT(d) "v_add_u32 " d ", 0x12345, " d "\n"
+#define I_CNDMASK_E64(d) "v_cndmask_b32_e64 " d ", " d ", %8, s[20:21]\n"
+#define I_CMP_CNDMASK(d) "v_cmp_gt_u32 vcc, " d ", %8\n v_cndmask_b32 " d ", " d ", %9, vcc\n"
+#define I_BITOP3(d) "v_bitop3_b32 " d ", " d ", %8, %9 bitop3:0x96\n"
+#define I_CVT_F32_U32_SDWA(d) "v_cvt_f32_u32_sdwa " d ", " d " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n"
+#define I_LSHLREV_V(d) "v_lshlrev_b32 " d ", %8, " d "\n"
+#define I_LSHRREV_V(d) "v_lshrrev_b32 " d ", %8, " d "\n"
+#define I_SUB_U16(d) "v_sub_u16 " d ", " d ", %8\n"
+#define I_MAX_I16(d) "v_max_i16 " d ", " d ", %8\n"
+#define I_MUL_LO_U16(d) "v_mul_lo_u16 " d ", " d ", %8\n"
+#define I_LSHRREV_B16(d) "v_lshrrev_b16 " d ", 3, " d "\n"
+#define I_SUBREV_U32(d) "v_subrev_u32 " d ", %8, " d "\n"
+#define I_MIN_F16(d) "v_min_f16 " d ", " d ", %8\n"
+#define I_ADD_F16(d) "v_add_f16 " d ", " d ", %8\n"
 #define I_READLANE(d) "v_readlane_b32 s20, " d ", 3\n"
 
 KERNEL32(fma_f32, I_FMA_F32) KERNEL32(mac_f32, I_MAC_F32) KERNEL32(add_f32, I_ADD_F32) KERNEL32(mul_f32, I_MUL_F32)
@@ -178,6 +197,12 @@ KERNEL32(pk_mad_u16, I_PK_MAD_U16) KERNEL32(pk_lshrrev_b16, I_PK_LSHRREV_B16) KE
 KERNEL32(add_u32_sdwa, I_ADD_U32_SDWA) KERNEL32(max_u16_sdwa, I_MAX_U16_SDWA) KERNEL32(mov_dpp_row_shr, I_MOV_DPP_SHR)
 KERNEL32(add_u32_dpp_row_shr, I_ADD_DPP_SHR) KERNEL32(mov_dpp_row_bcast, I_MOV_DPP_BCAST) KERNEL32(add_u32_sgpr_src, I_ADD_U32_S)
 KERNEL32(readlane_b32, I_READLANE)
+KERNEL32(fmac_f32_sgpr, I_FMAC_F32_S) KERNEL32(fma_f32_sgpr, I_FMA_F32_S) KERNEL32(mul_f32_sgpr, I_MUL_F32_S) KERNEL32(and_b32_sgpr, I_AND_S)
+KERNEL32(and_b32_literal, I_AND_LIT) KERNEL32(add_u32_literal, I_ADD_LIT) KERNEL32(cndmask_e64_sgpr, I_CNDMASK_E64)
+KERNEL32(cmp_then_cndmask, I_CMP_CNDMASK) KERNEL32(bitop3_b32, I_BITOP3) KERNEL32(cvt_f32_u32_sdwa, I_CVT_F32_U32_SDWA)
+KERNEL32(lshlrev_b32_vsrc, I_LSHLREV_V) KERNEL32(lshrrev_b32_vsrc, I_LSHRREV_V) KERNEL32(sub_u16, I_SUB_U16) KERNEL32(max_i16, I_MAX_I16)
+KERNEL32(mul_lo_u16, I_MUL_LO_U16) KERNEL32(lshrrev_b16, I_LSHRREV_B16) KERNEL32(subrev_u32, I_SUBREV_U32) KERNEL32(min_f16, I_MIN_F16)
+KERNEL32(add_f16, I_ADD_F16)
 
 typedef void (*kern_t)(unsigned*, int, unsigned long long*);
 struct Entry { const char* name; kern_t k; };
@@ -197,6 +222,9 @@ static const Entry entries[] = {
     E(pk_lshrrev_b16), E(pk_ashrrev_i16),
     E(add_u32_sdwa), E(max_u16_sdwa), E(mov_dpp_row_shr), E(add_u32_dpp_row_shr), E(mov_dpp_row_bcast), E(add_u32_sgpr_src),
     E(readlane_b32),
+    E(fmac_f32_sgpr), E(fma_f32_sgpr), E(mul_f32_sgpr), E(and_b32_sgpr), E(and_b32_literal), E(add_u32_literal), E(cndmask_e64_sgpr),
+    E(cmp_then_cndmask), E(bitop3_b32), E(cvt_f32_u32_sdwa), E(lshlrev_b32_vsrc), E(lshrrev_b32_vsrc), E(sub_u16), E(max_i16),
+    E(mul_lo_u16), E(lshrrev_b16), E(subrev_u32), E(min_f16), E(add_f16),
 };
 
 int main(int argc, char** argv)
