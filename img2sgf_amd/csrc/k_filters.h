@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ de
 // and 63 load theirs).  All arithmetic is FLOAT: measured on MI355X (profiles/r02_a_valu_rate_*.txt) v_add/mul/fma_f32 issue
 // at the full rate while every integer multiply, min/max, bit-field or packed instruction takes twice as long, and the
 // Gaussians are exact in f32: taps sum to 256 per axis, so every partial sum is an integer <= 255 * 256 * 256 < 2^24, and
-// (a + 32768) >> 16 = trunc(a * 2^-16 + 0.5) with both operations exact (the sum has at most 24 significant bits).
+// (a + 32768) >> 16 = trunc(a * 2^-16 + 0.5) with both operations exact (the sum has at most 24 significant bits); the
+// 2^-16 is folded into the taps as 2^-8 per pass, which only moves exponents.
 //   horizontal: pair sums p[-k] + p[k] shared by the three kernels, then 2 / 3 / 4 multiply-adds;
 //   vertical:   the horizontal results of the last 7 rows live in a register ring (statically indexed: the row loop is
 //               unrolled by 7), same pairing;
@@ -179,12 +180,52 @@ template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v)
 }
 #endif
 #define bl_f(v, byte) bl_fb<byte>(v)
+// Neighbour lanes' dwords: DPP whole-wave shifts (one VALU move each) instead of a round trip through the LDS crossbar.
+// Loads go through the global address space with a uniform base + 32-bit lane offset (the pointer comes out of the
+// descriptor table, so the compiler would otherwise issue FLAT loads, which also wait on the LDS counter).
+#ifdef HIPEMU
+__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v) { return (unsigned)__shfl_up((int)v, 1); }
+__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v) { return (unsigned)__shfl_down((int)v, 1); }
+__device__ __forceinline__ unsigned bl_load(const uint8_t* base, unsigned off) { return *reinterpret_cast<const unsigned*>(base + off); }
+__device__ __forceinline__ void bl_store(uint8_t* base, unsigned off, unsigned v) { *reinterpret_cast<unsigned*>(base + off) = v; }
+#else
+__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+__device__ __forceinline__ unsigned bl_load(const uint8_t* base, unsigned off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) unsigned*>(
+        (const __attribute__((address_space(1))) uint8_t*)base + off);
+}
+__device__ __forceinline__ void bl_store(uint8_t* base, unsigned off, unsigned v)
+{
+    *reinterpret_cast<__attribute__((address_space(1))) unsigned*>((__attribute__((address_space(1))) uint8_t*)base + off) = v;
+}
+#endif
+// "The prefetched registers are needed HERE": an empty statement that consumes them, so that the wait for the loads is placed
+// at this point.  On gfx9 loads and stores retire in order through one counter and the compiler, after the branches around
+// the predicated stores, must assume none of them is pending: a wait for last row's load placed AFTER this row's stores
+// therefore drains the stores as well (measured: 41 % of all wave cycles in s_waitcnt).  Waiting for the prefetch first and
+// storing afterwards leaves the stores a whole row of arithmetic to complete.
+#ifdef HIPEMU
+#define BL_CONSUME(a, b) do { } while (0)
+#define BL_SCHED_FENCE() do { } while (0)
+#else
+#define BL_CONSUME(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define BL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+// BORDER_REFLECT_101 of a row index that moves by one per step: (row, direction) instead of a modulo per row
+struct BlReflect {
+    int y, dir, n;
+    __device__ __forceinline__ void init(int p, int n_) { n = n_; y = reflect101(p, n_); dir = 1;
+        if (n_ > 1) { const int per = 2 * n_ - 2; int q = p % per; if (q < 0) q += per; dir = q < n_ - 1 ? 1 : -1; if (q == 0) dir = 1; } }
+    __device__ __forceinline__ void step() { if (n > 1) { y += dir; if (y == n - 1) dir = -1; else if (y == 0) dir = 1; } }
+};
 __device__ __forceinline__ unsigned bl_pack(float a, float b, float c, float d)
 {
     return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24);
 }
 // (acc + 32768) >> 16 of the exact integer acc held in a float
-__device__ __forceinline__ float bl_round16(float acc, float k16) { return __builtin_fmaf(acc, k16, 0.5f); }   // bl_pack truncates
+__device__ __forceinline__ float bl_round16(float acc16) { return acc16 + 0.5f; }   // acc16 = acc * 2^-16 (exact); bl_pack truncates
 
 // 3x3 medians of 4 adjacent pixels from three rows of 6 pixels (x0-1 .. x0+4), packed into one dword.  Integers: the
 // three-operand min / med / max instructions cost the same for floats and ints, and float min / max would first have to
@@ -215,15 +256,19 @@ __device__ __forceinline__ void bl_median_pixels(unsigned L, unsigned M, unsigne
     F[5] = (int)(mr & 0xffu);
 }
 
-__global__ __launch_bounds__(256, 3) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
+#ifndef BL_WAVES
+#define BL_WAVES 3
+#endif
+__global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
                                                  uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
                                                  BlurTaps tps, int gx, int gy)
 {
+    // taps scaled by 2^-8 (exact), used in both passes: the vertical sums then are acc * 2^-16 without a final multiply
     BlurTaps tp;
-    tp.c3 = bl_vgpr(tps.c3); tp.a3 = bl_vgpr(tps.a3);
-    tp.c5 = bl_vgpr(tps.c5); tp.a5 = bl_vgpr(tps.a5); tp.b5 = bl_vgpr(tps.b5);
-    tp.c7 = bl_vgpr(tps.c7); tp.a7 = bl_vgpr(tps.a7); tp.b7 = bl_vgpr(tps.b7); tp.d7 = bl_vgpr(tps.d7);
-    const float k16 = bl_vgpr(1.0f / 65536.0f);
+    constexpr float S = 1.0f / 256.0f;
+    tp.c3 = bl_vgpr(tps.c3 * S); tp.a3 = bl_vgpr(tps.a3 * S);
+    tp.c5 = bl_vgpr(tps.c5 * S); tp.a5 = bl_vgpr(tps.a5 * S); tp.b5 = bl_vgpr(tps.b5 * S);
+    tp.c7 = bl_vgpr(tps.c7 * S); tp.a7 = bl_vgpr(tps.a7 * S); tp.b7 = bl_vgpr(tps.b7 * S); tp.d7 = bl_vgpr(tps.d7 * S);
     // block = 4 wavefronts = 4 consecutive 256-pixel column groups of one band of BL_R rows
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z;
@@ -241,7 +286,9 @@ __global__ __launch_bounds__(256, 3) void k_blur(const ImgDesc* __restrict__ des
     // per-lane border selectors: byte k of the (L, M, R) triple is pixel x0 - 4 + k
     const bool fix_lane = active && (x0 - 3 < 0 || x0 + 6 >= w);
     const bool fix = __any(fix_lane ? 1 : 0) != 0;
-    unsigned gA[3] = {0x03020100u, 0x07060504u, 0x0c0c0c0cu}, gB[3] = {0x03020100u, 0x03020100u, 0x07060504u};
+    // Gaussian: L' and M' only ever draw on (L, M) -- a reflection never reaches further than the own dword's neighbour --
+    // R' may need all three dwords (two permutes).  Median: L', M' from (L, M), R' from (M, R).
+    unsigned gA[3] = {0x03020100u, 0x07060504u, 0x0c0c0c0cu}, gB2 = 0x07060504u;
     unsigned mS[3] = {0x03020100u, 0x07060504u, 0x07060504u};
     if (fix_lane) {
 #pragma unroll
@@ -253,19 +300,22 @@ __global__ __launch_bounds__(256, 3) void k_blur(const ImgDesc* __restrict__ des
                 int sg = reflect101(p, w) - (x0 - 4), sm = iclamp(p, 0, w - 1) - (x0 - 4);
                 if (sg < 0 || sg > 11) sg = 4;                        // a pixel no valid output of this lane needs
                 if (sm < 0 || sm > 11) sm = 4;
-                a |= (unsigned)(sg < 8 ? sg : 0x0c) << (8 * j);
+                a |= (unsigned)(sg < 8 ? sg : (d < 2 ? 4 : 0x0c)) << (8 * j);
                 bsel |= (unsigned)(sg < 8 ? j : sg - 4) << (8 * j);
                 // median: sources of L' and M' lie in (L, M), sources of R' in (M, R)
                 const int ms = d < 2 ? sm : sm - 4;
                 m |= (unsigned)(ms < 0 || ms > 7 ? 4 : ms) << (8 * j);
             }
-            gA[d] = a; gB[d] = bsel; mS[d] = m;
+            gA[d] = a; mS[d] = m;
+            if (d == 2) gB2 = bsel;
         }
     }
 
-    // one dword of a row for this lane, plus the edge dword of lanes 0 / 63 (their outer neighbour)
+    // one dword of a row for this lane, plus the edge dword of lanes 0 / 63 (their outer neighbour).  The loads are
+    // UNCONDITIONAL (lanes without a valid column read offset 0 of the row): a predicated load keeps the old register value
+    // for the other lanes, which makes the compiler wait for the previous load before it issues the next one.
     const bool has_e = (lane == 0 && x0 >= 4) || (lane == 63 && x0 + 4 < w);
-    const int xe = lane == 0 ? x0 - 4 : x0 + 4;
+    const unsigned xm = active ? (unsigned)x0 : 0u, xe = has_e ? (unsigned)(lane == 0 ? x0 - 4 : x0 + 4) : 0u;
 
     float H3[7][4], H5[7][4], H7[7][4];        // horizontal results of the last 7 input rows, slot = row index mod 7
     int F1[6], F2[6];                           // median ring: pixels x0-1 .. x0+4 of the two previous rows
@@ -277,39 +327,45 @@ __global__ __launch_bounds__(256, 3) void k_blur(const ImgDesc* __restrict__ des
     for (int i = 0; i < 6; i++) { F1[i] = 0; F2[i] = 0; }
     if (y0 == 0) {
         // BORDER_REPLICATE above the image: the ring starts out holding row 0 as "row -1"
-        unsigned M = 0, E = 0;
-        if (active) M = *reinterpret_cast<const unsigned*>(src + x0);
-        if (has_e) E = *reinterpret_cast<const unsigned*>(src + xe);
-        const unsigned up = (unsigned)__shfl_up((int)M, 1), dn = (unsigned)__shfl_down((int)M, 1);
+        const unsigned M = bl_load(src, xm), E = bl_load(src, xe);
+        const unsigned up = bl_from_prev_lane(M), dn = bl_from_next_lane(M);
         bl_median_pixels(lane == 0 ? E : up, M, lane == 63 ? E : dn, fix, mS, F1);
     }
 
-    unsigned nM = 0, nE = 0;
+    // the loads of row t + 1 are in flight while row t is computed
+    BlReflect ry;
+    ry.init(y0 - 3, h);
+    unsigned nM, nE;
     {
-        const uint8_t* rp = src + rowoff(reflect101(y0 - 3, h), sp);
-        if (active) nM = *reinterpret_cast<const unsigned*>(rp + x0);
-        if (has_e) nE = *reinterpret_cast<const unsigned*>(rp + xe);
+        const uint8_t* rp = src + rowoff(ry.y, sp);
+        nM = bl_load(rp, xm);
+        nE = bl_load(rp, xe);
     }
     static_assert((BL_R + 6) % 7 == 0, "the row loop is unrolled by the ring depth");
     const int t_end = imin(BL_R + 6, h + 3 - (y0 - 3));               // input rows beyond h + 2 feed no output of this band
+    uint8_t* const o_m = med3 + obase;
+    uint8_t* const o_3 = out3 + obase;
+    uint8_t* const o_5 = out5 + obase;
+    uint8_t* const o_7 = out7 + obase;
     for (int t0 = 0; t0 < t_end; t0 += 7) {
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             const int t = t0 + u;
             const int yi = y0 - 3 + t;
             const unsigned M = nM, E = nE;
-            {                                                          // next row's loads are in flight while this one is computed
-                const uint8_t* rp = src + rowoff(reflect101(yi + 1, h), sp);
-                if (active) nM = *reinterpret_cast<const unsigned*>(rp + x0);
-                if (has_e) nE = *reinterpret_cast<const unsigned*>(rp + xe);
+            {
+                ry.step();
+                const uint8_t* rp = src + rowoff(ry.y, sp);
+                nM = bl_load(rp, xm);
+                nE = bl_load(rp, xe);
             }
-            const unsigned up = (unsigned)__shfl_up((int)M, 1), dn = (unsigned)__shfl_down((int)M, 1);
+            const unsigned up = bl_from_prev_lane(M), dn = bl_from_next_lane(M);
             const unsigned L = lane == 0 ? E : up, R = lane == 63 ? E : dn;
             unsigned gl = L, gm = M, gr = R;
             if (fix) {
-                gl = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[0]), gB[0]);
-                gm = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[1]), gB[1]);
-                gr = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[2]), gB[2]);
+                gl = __builtin_amdgcn_perm(M, L, gA[0]);
+                gm = __builtin_amdgcn_perm(M, L, gA[1]);
+                gr = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[2]), gB2);
             }
             float f[10];                                              // pixels x0 - 3 .. x0 + 6
             f[0] = bl_f(gl, 1); f[1] = bl_f(gl, 2); f[2] = bl_f(gl, 3);
@@ -324,42 +380,53 @@ __global__ __launch_bounds__(256, 3) void k_blur(const ImgDesc* __restrict__ des
                 H5[u][q] = __builtin_fmaf(tp.b5, s2, __builtin_fmaf(tp.a5, s1, tp.c5 * c));
                 H7[u][q] = __builtin_fmaf(tp.d7, s3, __builtin_fmaf(tp.b7, s2, __builtin_fmaf(tp.a7, s1, tp.c7 * c)));
             }
+            unsigned om = 0, om2 = 0;
+            bool st_m = false, st_m2 = false;
             // 3x3 median: image row yi completes output row yi - 1 (rows yi - 2, yi - 1, yi = F2, F1, F0); the last image
             // row also completes itself (BORDER_REPLICATE below the image: rows h - 2, h - 1, h - 1)
             if (yi >= 0 && yi < h) {
                 int F0[6];
                 bl_median_pixels(L, M, R, fix, mS, F0);
                 const int ym = yi - 1;
-                if (ym >= y0 && ym < y0 + BL_R) {
-                    const unsigned o = bl_median_row(F2, F1, F0);
-                    if (active) *reinterpret_cast<unsigned*>(med3 + obase + rowoff(ym, g.pitch) + x0) = o;
-                }
-                if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) {
-                    const unsigned o = bl_median_row(F1, F0, F0);
-                    if (active) *reinterpret_cast<unsigned*>(med3 + obase + rowoff(yi, g.pitch) + x0) = o;
-                }
+                if (ym >= y0 && ym < y0 + BL_R) { om = bl_median_row(F2, F1, F0); st_m = true; }
+                if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) { om2 = bl_median_row(F1, F0, F0); st_m2 = true; }
 #pragma unroll
                 for (int i = 0; i < 6; i++) { F2[i] = F1[i]; F1[i] = F0[i]; }
             }
             // vertical pass: output row yo = yi - 3 from ring slots t-6 .. t (centre t-3)
             const int yo = yi - 3;
-            if (t >= 6 && yo < h && active) {
+            unsigned o3w = 0, o5w = 0, o7w = 0;
+            const bool st_g = t >= 6 && yo < h;
+            if (st_g) {
                 constexpr int NS = 7;
                 const int c = (u + 4) % NS, p1 = (u + 5) % NS, m1 = (u + 3) % NS, p2 = (u + 6) % NS, m2 = (u + 2) % NS, p3 = u, m3 = (u + 1) % NS;
                 float r3[4], r5[4], r7[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    r3[q] = bl_round16(__builtin_fmaf(tp.a3, H3[p1][q] + H3[m1][q], tp.c3 * H3[c][q]), k16);
+                    r3[q] = bl_round16(__builtin_fmaf(tp.a3, H3[p1][q] + H3[m1][q], tp.c3 * H3[c][q]));
                     r5[q] = bl_round16(__builtin_fmaf(tp.b5, H5[p2][q] + H5[m2][q],
-                                                      __builtin_fmaf(tp.a5, H5[p1][q] + H5[m1][q], tp.c5 * H5[c][q])), k16);
+                                                      __builtin_fmaf(tp.a5, H5[p1][q] + H5[m1][q], tp.c5 * H5[c][q])));
                     r7[q] = bl_round16(__builtin_fmaf(tp.d7, H7[p3][q] + H7[m3][q],
                                                       __builtin_fmaf(tp.b7, H7[p2][q] + H7[m2][q],
-                                                                     __builtin_fmaf(tp.a7, H7[p1][q] + H7[m1][q], tp.c7 * H7[c][q]))), k16);
+                                                                     __builtin_fmaf(tp.a7, H7[p1][q] + H7[m1][q], tp.c7 * H7[c][q]))));
                 }
-                const int off = rowoff(yo, g.pitch) + x0;
-                *reinterpret_cast<unsigned*>(out3 + obase + off) = bl_pack(r3[0], r3[1], r3[2], r3[3]);
-                *reinterpret_cast<unsigned*>(out5 + obase + off) = bl_pack(r5[0], r5[1], r5[2], r5[3]);
-                *reinterpret_cast<unsigned*>(out7 + obase + off) = bl_pack(r7[0], r7[1], r7[2], r7[3]);
+                o3w = bl_pack(r3[0], r3[1], r3[2], r3[3]);
+                o5w = bl_pack(r5[0], r5[1], r5[2], r5[3]);
+                o7w = bl_pack(r7[0], r7[1], r7[2], r7[3]);
+            }
+            // the stores of this row go out AFTER the wait for the next row's pixels (see BL_CONSUME)
+            BL_SCHED_FENCE();
+            BL_CONSUME(nM, nE);
+            BL_SCHED_FENCE();
+            if (active) {
+                if (st_m) bl_store(o_m + rowoff(yi - 1, g.pitch), xm, om);
+                if (st_m2) bl_store(o_m + rowoff(yi, g.pitch), xm, om2);
+                if (st_g) {
+                    const int off = rowoff(yo, g.pitch);
+                    bl_store(o_3 + off, xm, o3w);
+                    bl_store(o_5 + off, xm, o5w);
+                    bl_store(o_7 + off, xm, o7w);
+                }
             }
         }
     }
