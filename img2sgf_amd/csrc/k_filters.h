@@ -483,37 +483,35 @@ __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ des
 }
 
 // 5x5 and 7x7 together, bit-serial on bit planes.
-// The tile is transposed once into 8 bit planes (one 64-bit word per plane and row, bit i = pixel x0-4+i).  A thread
-// owns 2 adjacent columns and walks down 8 output rows; per plane it keeps the window as a bit mask (7 rows x 7 bits in
-// two dwords, 5 x 5 bits in one) held as a ring of row slots, so moving down one row = one bit-field insert.
-// The median is then read off MSB first: with A = elements still tied with the prefix and nh = elements already known
-// to be larger, bit b of the median is 1 iff popcount(A & P_b) + nh >= N - N/2; A shrinks to the matching half.
-// ~230 integer ops per pixel for both medians instead of ~1200 for per-pixel counting.
+// The tile is transposed once into 8 bit planes (one 64-bit word per plane and row, bit i = pixel x0-4+i).  A thread owns 2
+// adjacent columns and walks down M_RPT output rows.  Per plane it keeps ONE window ring for both pixels and both medians:
+// 7 rows x 8 bits (columns c-3 .. c+4) in two dwords, one byte per row, slot = row mod 7 (static: the walk is fully
+// unrolled), so a new row costs one 64-bit shift and one byte permute per plane.  The four medians of a row differ only in
+// their candidate masks over that ring: 7x7 of the left pixel = bits 0-6 of all 7 bytes, of the right pixel bits 1-7; 5x5 =
+// the 5 middle rows, bits 1-5 / 2-6 (a popcount does not care where the bits sit).
+// The median is read off MSB first: c = candidates with bit b set; bit b of the median is 1 iff c >= need (need = rank from
+// the top still to be found among the candidates, 25 resp. 13 at the start); the candidates shrink to the matching half and,
+// for a 0 bit, need drops by c.  All bookkeeping is sign-mask arithmetic on sub / shift-right / and / xor -- the full-rate
+// instructions of this chip (profiles/r02_a_valu_rate_*.txt) -- instead of compares and selects (half rate); the only
+// half-rate instructions left in a round are the two popcounts.  Exact for any input.
 constexpr int MT_W = 56, MT_H = 72, M_RPT = 8;
 constexpr int M_ROWS = MT_H + 6, M_SSTR = 17;
 
-template <int N, int NLO>
-__device__ __forceinline__ unsigned median_planes(const unsigned (&plo)[8], const unsigned (&phi)[8])
+struct MedState { unsigned alo, ahi; int need; unsigned r; };
+
+// one bit-plane round for one (pixel, window): plo / phi = the plane's ring words
+__device__ __forceinline__ void med_round(MedState& s, unsigned plo, unsigned phi)
 {
-    // N elements: NLO bits in plo, N - NLO bits in phi (phi unused when N == NLO)
-    unsigned alo = NLO >= 32 ? 0xffffffffu : ((1u << NLO) - 1u);
-    unsigned ahi = (N - NLO) > 0 ? ((1u << (N - NLO)) - 1u) : 0u;
-    int nh = 0;
-    unsigned m = 0;
-#pragma unroll
-    for (int bit = 7; bit >= 0; bit--) {
-        const unsigned tl = alo & plo[bit];
-        const unsigned th = (N - NLO) > 0 ? (ahi & phi[bit]) : 0u;
-        int ones = __popc(tl) + nh;
-        if ((N - NLO) > 0) ones += __popc(th);
-        const bool one = ones >= N - N / 2;
-        m = (m << 1) | (one ? 1u : 0u);
-        const unsigned nl = alo ^ tl, nhh = ahi ^ th;
-        alo = one ? tl : nl;
-        if ((N - NLO) > 0) ahi = one ? th : nhh;
-        nh = one ? nh : ones;
-    }
-    return m;
+    const int c = __popc(s.alo & plo) + __popc(s.ahi & phi);
+    int d = c - s.need;
+#ifndef HIPEMU
+    asm("" : "+v"(d));                                 // opaque: otherwise the compiler turns the sign mask back into compare + selects
+#endif
+    const int nm = d >> 31;                            // all ones iff c < need: the median's bit is 0
+    s.alo &= plo ^ (unsigned)nm;                       // keep the candidates whose bit equals the median's
+    s.ahi &= phi ^ (unsigned)nm;
+    s.need -= c & nm;                                  // bit 0: the c candidates with a 1 are larger than the median
+    s.r = s.r + s.r - (unsigned)nm;                    // collects the COMPLEMENT of the median, MSB first
 }
 
 __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
@@ -548,48 +546,51 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
     const int cg = tid % 28, rg = tid / 28;
     const int c = 2 * cg, r0 = rg * M_RPT;           // first tile column / output row of this thread
     if (x0 + c >= w || y0 + r0 >= h) return;
-    unsigned a7lo[2][8], a7hi[2][8], a5[2][8], prev[8];
+    const int pos = c + 1;                           // plane bit of tile column c - 3
+    unsigned rlo[8], rhi[8];                         // window ring per plane: byte k of rlo = row slot k, of rhi = slot 4 + k
 #pragma unroll
-    for (int p = 0; p < 8; p++) { a7lo[0][p] = a7lo[1][p] = a7hi[0][p] = a7hi[1][p] = a5[0][p] = a5[1][p] = 0; prev[p] = 0; }
+    for (int p = 0; p < 8; p++) { rlo[p] = 0; rhi[p] = 0; }
     uint8_t* o5 = out5 + (size_t)b * g.slot;
     uint8_t* o7 = out7 + (size_t)b * g.slot;
 #pragma unroll
     for (int t = 0; t < M_RPT + 6; t++) {
-        // source tile row r0 + t enters the 7-row ring (slot t % 7); row r0 + t - 1 enters the 5-row ring (slot (t-1) % 5)
+        // source tile row r0 + t enters ring slot t % 7
+        constexpr unsigned SEL[4] = {0x03020104u, 0x03020400u, 0x03040100u, 0x04020100u};     // byte 0 of S0 into byte k of S1
+        const int slot = t % 7;
 #pragma unroll
         for (int p = 0; p < 8; p++) {
-            const unsigned long long rw = s_pl[p * M_ROWS + r0 + t];
-            const unsigned seg = (unsigned)(rw >> (c + 1)) & 0xffu;    // bits of tile columns c-3 .. c+4
-            const int s7 = t % 7;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const unsigned v7 = (seg >> q) & 0x7fu;
-                if (s7 < 4) a7lo[q][p] = (a7lo[q][p] & ~(0x7fu << (7 * s7))) | (v7 << (7 * s7));
-                else a7hi[q][p] = (a7hi[q][p] & ~(0x7fu << (7 * (s7 - 4)))) | (v7 << (7 * (s7 - 4)));
-                if (t >= 1) {
-                    const int s5 = (t - 1) % 5;
-                    const unsigned v5 = (prev[p] >> (q + 1)) & 0x1fu;
-                    a5[q][p] = (a5[q][p] & ~(0x1fu << (5 * s5))) | (v5 << (5 * s5));
-                }
-            }
-            prev[p] = seg;
+            const unsigned seg = (unsigned)(s_pl[p * M_ROWS + r0 + t] >> pos);                 // byte 0 = columns c-3 .. c+4
+            if (slot < 4) rlo[p] = __builtin_amdgcn_perm(seg, rlo[p], SEL[slot]);
+            else rhi[p] = __builtin_amdgcn_perm(seg, rhi[p], SEL[slot - 4]);
         }
         if (t >= 6) {
             const int y = y0 + r0 + (t - 6);
             if (y < h) {
-                unsigned m7[2], m5[2];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    m7[q] = median_planes<49, 28>(a7lo[q], a7hi[q]);
-                    m5[q] = median_planes<25, 25>(a5[q], a5[q]);
+                // candidate masks: 7x7 = all 7 slots; 5x5 = the 5 middle rows (not the oldest slot (t+1)%7, not the newest t%7)
+                unsigned rows5lo = 0xffffffffu, rows5hi = 0x00ffffffu;
+                {
+                    const int o = (t + 1) % 7, nw = t % 7;
+                    if (o < 4) rows5lo &= ~(0xffu << (8 * o)); else rows5hi &= ~(0xffu << (8 * (o - 4)));
+                    if (nw < 4) rows5lo &= ~(0xffu << (8 * nw)); else rows5hi &= ~(0xffu << (8 * (nw - 4)));
                 }
+                MedState m7a = {0x7f7f7f7fu, 0x007f7f7fu, 25, 0}, m7b = {0xfefefefeu, 0x00fefefeu, 25, 0};
+                MedState m5a = {0x3e3e3e3eu & rows5lo, 0x3e3e3e3eu & rows5hi, 13, 0}, m5b = {0x7c7c7c7cu & rows5lo, 0x7c7c7c7cu & rows5hi, 13, 0};
+#pragma unroll
+                for (int bit = 7; bit >= 0; bit--) {
+                    med_round(m7a, rlo[bit], rhi[bit]);
+                    med_round(m7b, rlo[bit], rhi[bit]);
+                    med_round(m5a, rlo[bit], rhi[bit]);
+                    med_round(m5b, rlo[bit], rhi[bit]);
+                }
+                const unsigned v7 = ((m7a.r ^ 0xffu) & 0xffu) | (((m7b.r ^ 0xffu) & 0xffu) << 8);
+                const unsigned v5 = ((m5a.r ^ 0xffu) & 0xffu) | (((m5b.r ^ 0xffu) & 0xffu) << 8);
                 const int x = x0 + c;
                 if (x + 1 < w) {
-                    *reinterpret_cast<unsigned short*>(o5 + rowoff(y, g.pitch) + x) = (unsigned short)(m5[0] | (m5[1] << 8));
-                    *reinterpret_cast<unsigned short*>(o7 + rowoff(y, g.pitch) + x) = (unsigned short)(m7[0] | (m7[1] << 8));
+                    *reinterpret_cast<unsigned short*>(o5 + rowoff(y, g.pitch) + x) = (unsigned short)v5;
+                    *reinterpret_cast<unsigned short*>(o7 + rowoff(y, g.pitch) + x) = (unsigned short)v7;
                 } else {
-                    o5[rowoff(y, g.pitch) + x] = (uint8_t)m5[0];
-                    o7[rowoff(y, g.pitch) + x] = (uint8_t)m7[0];
+                    o5[rowoff(y, g.pitch) + x] = (uint8_t)v5;
+                    o7[rowoff(y, g.pitch) + x] = (uint8_t)v7;
                 }
             }
         }
