@@ -60,4 +60,9 @@ def check_find_lines(det):
     # a non-default angle tolerance changes the angle set of the three HoughLines calls
     p = pipeline.Params(angle_tolerance=1.4)
     hl2, _ = pipeline.find_all_lines(removed, thr, params=p, detector=det)
-    assert len(hl2) >= len(hl)
+    import math
+    from oracle import cv_oracle as cvo
+    dlt = math.pi / 180 * 1.4
+    want = cvo.hough_lines(removed, 1, math.pi / 180.0, thr, math.pi / 2 - dlt, math.pi / 2 + dlt)
+    want = np.zeros(0, np.float32) if want is None else want[:, 0, 0]
+    np.testing.assert_array_equal(np.asarray(hl2, np.float32).reshape(-1), want)
