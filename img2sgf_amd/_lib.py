@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libi2s_hip.so")
 
 BOARD_SIZE = 19
 NSLOTS = 10
-MAX_CIRCLES = 4096
+MAX_CIRCLES = 16384
 MAX_LINES = 1024
 MAX_CENTRES = 256
 PLANE_NAMES = {"grey": 0, "edges": 1, "median3": 2, "gauss3": 3, "median5": 4, "gauss5": 5, "median7": 6,
@@ -82,7 +82,7 @@ class I2sXform(C.Structure):
 
 
 assert C.sizeof(I2sBoard) == 384
-assert C.sizeof(I2sResult) == 73384
+assert C.sizeof(I2sResult) == 73384 + (16384 - 4096) * 13
 
 EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
            "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_jpeg_info", "i2s_detect_jpeg_batch",

@@ -176,6 +176,16 @@ static int create_impl(i2s_ctx* ctx)
     g.bins = g.bw * ((ctx->max_h + EB - 1) / EB);
     g.tw = (ctx->max_w + CT_W - 1) / CT_W;
     g.tiles = g.tw * ((ctx->max_h + CT_H - 1) / CT_H);
+    {
+        const long long area = (long long)ctx->max_w * ctx->max_h;
+        int f = (int)((area + (1 << 20) - 1) >> 20);
+        f = f < 1 ? 1 : (f > CAP_SCALE_MAX ? CAP_SCALE_MAX : f);
+        // accumulator maxima can be two orders of magnitude more numerous than circles (a ring of radius 5 under a 7x7 blur
+        // yields a cloud of them): one entry per 8 pixels of the largest image, never less than the round-1 constant
+        const long long cc = area / 8;
+        g.cent_cap = (int)(cc < CENT_UNIT ? CENT_UNIT : (cc > (1 << 22) ? (1 << 22) : cc));
+        g.est_cap = EST_UNIT * f; g.vcirc_cap = VCIRC_UNIT * f;
+    }
     const size_t nb = ctx->max_batch;
     I2S_HIP(hipMalloc(&ctx->d_lsum, nb * sizeof(unsigned long long)));
     I2S_HIP(hipMalloc(&ctx->d_tl_cnt, nb * g.tiles * sizeof(int)));
@@ -193,10 +203,10 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipHostMalloc(&ctx->h_jd, nb * sizeof(JpgDesc)));
     I2S_HIP(hipMalloc(&ctx->d_flags, 2 * HYST_MAX_PASSES * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_flags, 2 * sizeof(int)));
-    I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * CENT_CAP * sizeof(unsigned)));
+    I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * g.cent_cap * sizeof(unsigned)));
     I2S_HIP(hipMalloc(&ctx->d_counts, counts_bytes(ctx)));
-    I2S_HIP(hipMalloc(&ctx->d_est_keys, nb * NVAR * EST_CAP * sizeof(unsigned long long)));
-    I2S_HIP(hipMalloc(&ctx->d_vcirc, nb * NVAR * VCIRC_CAP * 3 * sizeof(float)));
+    I2S_HIP(hipMalloc(&ctx->d_est_keys, nb * NVAR * g.est_cap * sizeof(unsigned long long)));
+    I2S_HIP(hipMalloc(&ctx->d_vcirc, nb * NVAR * g.vcirc_cap * 3 * sizeof(float)));
     I2S_HIP(hipMalloc(&ctx->d_bin_cnt, nb * NVAR * g.bins * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_bin_ent, nb * NVAR * g.bins * EB_CAP * sizeof(uint2)));
     ctx->lrow = (2 * (ctx->max_w + ctx->max_h) + 1 + 15) / 16 * 16;
@@ -459,8 +469,13 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                            ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
                            ctx->d_est_keys, est_count(ctx));
         I2S_SEG(11);
-        hipLaunchKernelGGL(k_circles_final, dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx),
-                           p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
+        if (g.est_cap <= EST_UNIT)
+            hipLaunchKernelGGL((k_circles_final<EST_UNIT, VCIRC_UNIT>), dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys,
+                               est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
+        else
+            hipLaunchKernelGGL((k_circles_final<EST_UNIT * CAP_SCALE_MAX, VCIRC_UNIT * CAP_SCALE_MAX>), dim3(nb * NVAR), dim3(FIN_THREADS),
+                               0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc,
+                               vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));
         I2S_SEG(12);
 

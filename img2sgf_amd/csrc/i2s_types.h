@@ -18,9 +18,15 @@ __device__ __host__ inline int slot_variant(int s)
     return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 0 : s == 3 ? 0 : s - 2;
 }
 
-constexpr int CENT_CAP = 8192;   // accumulator local maxima per (image, variant)
-constexpr int EST_CAP = 4096;    // supported circle estimates per (image, variant)
-constexpr int VCIRC_CAP = 2048;  // circles kept per (image, variant) after the min-dist pass
+// Capacities of the HoughCircles lists per (image, variant).  The reference's lists are unbounded (img2sgf.py:179-186); here
+// they are sized at i2s_create from the largest image the context accepts and carried in Geo: one accumulator maximum per 8
+// pixels; EST_UNIT / VCIRC_UNIT estimates / circles per started megapixel, up to CAP_SCALE_MAX units (the estimates of one
+// HoughCircles call are sorted in LDS) -- so a 2048 x 2048 page scan has four times the room of a 1024 x 1024 diagram.
+// An overflow is still reported (I2S_ST_CAPACITY), never truncated.
+constexpr int CENT_UNIT = 8192;   // accumulator local maxima: lower bound of the per-area capacity
+constexpr int EST_UNIT = 4096;    // supported circle estimates (k_circles_final sorts them in LDS: 8 bytes each)
+constexpr int VCIRC_UNIT = 2048;  // circles kept after the min-dist pass
+constexpr int CAP_SCALE_MAX = 4;
 
 // Per-image descriptor (device array, one per image of the current pass).
 struct ImgDesc {
@@ -42,6 +48,7 @@ struct Geo {
     int wmax;
     int bw, bins;         // edge bins per row / per plane (32x32-pixel cells)
     int tw, tiles;        // 64x32 Canny tiles per row / per plane (hysteresis work flags)
+    int cent_cap, est_cap, vcirc_cap;   // HoughCircles list capacities per (image, variant), see CENT_UNIT
     long long slot;       // pitch * hmax
 };
 

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_concat_circles(const ImgDesc* __restric
     if (s_off[NSLOT] < 0) return;
     for (int s = 0; s < NSLOT; s++) {
         const int n = s_off[s + 1] - s_off[s];
-        const float* src = vcirc + (size_t)(b * NVAR + slot_variant(s)) * VCIRC_CAP * 3;
+        const float* src = vcirc + (size_t)(b * NVAR + slot_variant(s)) * g.vcirc_cap * 3;
         float* dst = &R->circles[s_off[s]][0];
         for (int i = threadIdx.x; i < n * 3; i += 256) dst[i] = src[i];
         // erase box of circle (s_off[s] + i): r + 2 in float32, corners rounded half-to-even (img2sgf.py:193-195)

@@ -174,7 +174,7 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
 }
 
 // grid (tiles_x, tiles_y, nb * NVAR), block 512.
-// cent_list[(b * NVAR + v) * CENT_CAP + i] = x | y << 16 of an accumulator local maximum; cent_count likewise.
+// cent_list[(b * NVAR + v) * g.cent_cap + i] = x | y << 16 of an accumulator local maximum; cent_count likewise.
 // dbg_acc (optional): dense int32 accumulator, cell (x,y) of (b,v) at ((b * NVAR + v) * hmax + y) * pitch + x.
 //
 // Votes of one edge pixel: cells ((x*1024 +- r*sx) >> 10, (y*1024 +- r*sy) >> 10), r = min_r..max_r, that lie inside the
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
             if (a <= acc_thr || y >= h || y < 1) continue;
             if (a > I2S_CELL(tx - 1, ty) && a >= I2S_CELL(tx + 1, ty) && a > I2S_CELL(tx, ty - 1) && a >= I2S_CELL(tx, ty + 1)) {
                 const int k = atomicAdd(&cent_count[bv], 1);
-                if (k < CENT_CAP) cent_list[(size_t)bv * CENT_CAP + k] = (unsigned)x | ((unsigned)y << 16);
+                if (k < g.cent_cap) cent_list[(size_t)bv * g.cent_cap + k] = (unsigned)x | ((unsigned)y << 16);
             }
         }
     }
@@ -352,7 +352,7 @@ constexpr int RAD_LUT = 512;        // radius-bin table: K / 2 < max_r^2 / 2 <= 
 // The voting edge pixels near the centre come from the edge bins (the same set OpenCV keeps in `nz`); their distances
 // go into a 10-bins-per-pixel LDS histogram; the histogram scan (windows of 10 bins opened at every non-empty bin,
 // walking down from the largest radius) runs wave-uniformly on prefix sums + 64-bit occupancy masks.
-// est_keys[(b*NVAR+v) * EST_CAP + i], est_count[b*NVAR+v].
+// est_keys[(b*NVAR+v) * g.est_cap + i], est_count[b*NVAR+v].
 __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc, Geo g,
                                                 const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
                                                 const unsigned* __restrict__ cent_list, const int* __restrict__ cent_count,
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
     const int bv = blockIdx.y;
     const int b = bv / NVAR;
     const int w = desc[b].w, h = desc[b].h;
-    const int n = imin(cent_count[bv], CENT_CAP);
+    const int n = imin(cent_count[bv], g.cent_cap);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nBinsPerDr = 10;
     int nBins = __float2int_rn((float)(max_r - min_r) / 1.0f * (float)nBinsPerDr);
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
         __builtin_amdgcn_wave_barrier();
         int cxi = 0, cyi = 0;
         {
-            const unsigned e = cent_list[(size_t)bv * CENT_CAP + c];
+            const unsigned e = cent_list[(size_t)bv * g.cent_cap + c];
             cxi = (int)(e & 0xffffu); cyi = (int)(e >> 16);
             // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: at most 3 x 3 bins overlap that box.
             // Lane q fetches bin q's count, then all record loads of all bins are issued before any is consumed.
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
             }
             if (lane == 0 && maxCount > acc_thr) {
                 const int k = atomicAdd(&est_count[bv], 1);
-                if (k < EST_CAP) est_keys[(size_t)bv * EST_CAP + k] = est_key(imin(maxCount, 4095), sBest, cxi, cyi);
+                if (k < g.est_cap) est_keys[(size_t)bv * g.est_cap + k] = est_key(imin(maxCount, 4095), sBest, cxi, cyi);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -498,27 +498,30 @@ constexpr int FIN_THREADS = 1024;
 
 // grid (nb * NVAR), block FIN_THREADS.  Sorts the estimates (OpenCV's cmpAccum order), runs RemoveOverlaps (keep a circle
 // iff it is at least min_dist from every circle already kept) and writes circles (x, y, r) in output order.
-// vcirc[(bv * VCIRC_CAP + i) * 3], vcount[bv]; overflow[b] is set when a capacity was exceeded.
+// vcirc[(bv * g.vcirc_cap + i) * 3], vcount[bv]; overflow[b] is set when a capacity was exceeded.
+// ECAP / VCAP: compile-time capacities of the LDS arrays (>= g.est_cap / g.vcirc_cap); the host launches the instantiation that
+// fits the context's capacities, so that 1024 x 1024 contexts keep the small footprint (several workgroups per CU).
+template <int ECAP, int VCAP>
 __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned long long* __restrict__ est_keys,
                                                        const int* __restrict__ est_count, const int* __restrict__ cent_count,
                                                        float min_dist, int min_r,
                                                        float* __restrict__ vcirc, int* __restrict__ vcount, int* __restrict__ overflow)
 {
-    __shared__ unsigned long long s_key[EST_CAP];
-    __shared__ short s_kx[VCIRC_CAP];
+    __shared__ unsigned long long s_key[ECAP];
+    __shared__ short s_kx[VCAP];
     __shared__ int s_scan[FIN_THREADS];
-    __shared__ int s_flag;
+    __shared__ int s_flag[3];
     const int bv = blockIdx.x;
     const int b = bv / NVAR;
     const int tid = threadIdx.x;
     int n = est_count[bv];
-    if (cent_count[bv] > CENT_CAP || n > EST_CAP) {
+    if (cent_count[bv] > g.cent_cap || n > g.est_cap) {
         if (tid == 0) { overflow[b] = 1; vcount[bv] = 0; }
         return;
     }
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
-    for (int i = tid; i < np2; i += FIN_THREADS) s_key[i] = i < n ? est_keys[(size_t)bv * EST_CAP + i] : ~0ull;
+    for (int i = tid; i < np2; i += FIN_THREADS) s_key[i] = i < n ? est_keys[(size_t)bv * g.est_cap + i] : ~0ull;
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -535,9 +538,10 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
     // RemoveOverlaps: circle i is kept iff no KEPT circle j < i lies within min_dist.  Resolved in parallel rounds instead
     // of the sequential sweep: a candidate whose earlier neighbours (within min_dist) are all decided is decided itself;
     // clusters around one stone settle in 2-3 rounds.  The outcome is the sequential greedy's, by induction on i.
-    unsigned char* s_st = reinterpret_cast<unsigned char*>(s_kx);        // 0 undecided, 1 kept, 2 rejected (n <= EST_CAP bytes)
-    static_assert(sizeof(short) * VCIRC_CAP >= EST_CAP, "status bytes alias s_kx");
+    unsigned char* s_st = reinterpret_cast<unsigned char*>(s_kx);        // 0 undecided, 1 kept, 2 rejected (n <= ECAP bytes)
+    static_assert(sizeof(short) * VCAP >= ECAP, "status bytes alias s_kx");
     for (int i = tid; i < n; i += FIN_THREADS) s_st[i] = 0;
+    if (tid < 3) s_flag[tid] = 0;
     __syncthreads();
     const float md2 = min_dist * min_dist;
     for (int round = 0; round < n; round++) {
@@ -558,11 +562,12 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
             }
             if (verdict) s_st[i] = (unsigned char)verdict; else undecided_left = true;
         }
-        if (tid == 0) s_flag = 0;
+        // "somebody is still undecided" flag of this round: three slots in rotation, so that the slot of the next round can be
+        // cleared here without racing with threads that have not yet read the previous round's (one barrier per round)
+        if (undecided_left) s_flag[round % 3] = 1;
+        if (tid == 0) s_flag[(round + 1) % 3] = 0;
         __syncthreads();
-        if (undecided_left) s_flag = 1;
-        __syncthreads();
-        if (s_flag == 0) break;
+        if (s_flag[round % 3] == 0) break;
     }
     // ordered compaction of the kept circles (block-wide inclusive scan over chunks of FIN_THREADS candidates)
     int base = 0;
@@ -578,11 +583,11 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
             __syncthreads();
         }
         const int pos = base + s_scan[tid] - keep;
-        if (keep && pos < VCIRC_CAP) {
+        if (keep && pos < g.vcirc_cap) {
             const unsigned long long key = s_key[i];
             const int x = (int)((key >> 16) & 0xffffu), y = (int)(key & 0xffffu);
             const int sr = 1023 - (int)((key >> 32) & 0x3ffu);
-            float* o = vcirc + ((size_t)bv * VCIRC_CAP + pos) * 3;
+            float* o = vcirc + ((size_t)bv * g.vcirc_cap + pos) * 3;
             o[0] = ((float)x + 0.5f) * 1.0f;
             o[1] = ((float)y + 0.5f) * 1.0f;
             o[2] = (float)sr / 2.f / 10.f * 1.0f + (float)min_r;
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
         __syncthreads();
     }
     if (tid == 0) {
-        const bool over = base > VCIRC_CAP;
+        const bool over = base > g.vcirc_cap;
         vcount[bv] = over ? 0 : base;
         if (over) overflow[b] = 1;
     }

@@ -51,7 +51,7 @@ extern "C" {
 
 #define I2S_BOARD_SIZE 19      /* img2sgf.py:43 */
 #define I2S_NSLOTS 10          /* blur-bank slots, img2sgf.py:171-175 */
-#define I2S_MAX_CIRCLES 4096   /* concatenated circles per image (all 10 slots) */
+#define I2S_MAX_CIRCLES 16384  /* concatenated circles per image (all 10 slots) */
 #define I2S_MAX_LINES 1024     /* Hough-line peaks per direction */
 #define I2S_MAX_CENTRES 256    /* cluster centres / completed grid lines per direction */
 
@@ -78,7 +78,10 @@ enum {
     I2S_ST_V_TOO_WIDE = 8,
     I2S_ST_TOO_MANY_VLINES = 9,    /* hsize > 19, "Too many vertical lines!" 569 */
     I2S_ST_TOO_MANY_HLINES = 10,   /* vsize > 19, "Too many horizontal lines!" 571 */
-    I2S_ST_CAPACITY = 100          /* a fixed capacity (circles/lines/centres) overflowed: results invalid */
+    I2S_ST_CAPACITY = 100          /* a capacity overflowed: results invalid.  The reference's lists are unbounded; here: I2S_MAX_CIRCLES
+                                      concatenated circles and I2S_MAX_LINES peaks per direction in the record; per HoughCircles call
+                                      2048 circles and 4096 supported estimates PER STARTED MEGAPIXEL of the context's max_w x max_h
+                                      (up to 4x) and one accumulator maximum per 8 pixels: larger contexts have more room */
 };
 
 /* board cell values: BoardStates, img2sgf.py:82-83 */

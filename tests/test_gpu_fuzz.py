@@ -85,15 +85,16 @@ def test_fuzz_against_oracle(seed):
     dets = det.detect_batch(imgs, params, full=True)
     over = [k for k, d in enumerate(dets) if d.status == 100]
     if over:
-        # fixed capacities of the C ABI (include/i2s.h) are reported, never silently truncated: the oracle must agree that one
-        # of them was exceeded (4096 circles per image, 2048 per HoughCircles call, 4096 estimates, 8192 centre candidates)
+        # capacities (include/i2s.h: I2S_ST_CAPACITY) are reported, never silently truncated: the oracle must agree that one of
+        # them was exceeded (16384 circles per image; per HoughCircles call 2048 circles and 4096 supported estimates per
+        # started megapixel of the context -- these contexts are below one megapixel -- and max(8192, area / 8) accumulator maxima)
         from oracle import cv_oracle as cvo
         for k in over:
             ref = opipe.process_image(imgs[k], **okw)
             worst = max(len(c) for c in ref["circles_per_variant"])
             dbg = [cvo.hough_circles(b, *okw.get("hc", (10, 100, 30, 1, 30)), debug=True)[1] for b in ref["blurs"]]
-            assert (len(ref["circles_all"]) > 4096 or worst > 2048 or max(len(d["est"]) for d in dbg) > 4096
-                    or max(d["n_centers"] for d in dbg) > 8192), "capacity status without a capacity being exceeded"
+            assert (len(ref["circles_all"]) > 16384 or worst > 2048 or max(len(d["est"]) for d in dbg) > 4096
+                    or max(d["n_centers"] for d in dbg) > max(8192, det.max_w * det.max_h // 8)), "capacity status without a capacity being exceeded"
         imgs = [im for k, im in enumerate(imgs) if k not in over]
     if imgs:
         parity.run_and_compare(det, imgs, params=params, internals=okw == {}, oracle_kwargs=okw)

@@ -314,16 +314,35 @@ def test_streamed_host_batch_matches_single_stream():
 
 
 def test_large_images():
-    """Sizes beyond the benchmark's: a 2048x2048 mosaic of four diagrams, a 1536x2560 image and a 1100x1700 colour one (every
-    plane, circle, line and record against the oracle; all below the 4096-circle capacity)."""
+    """Sizes beyond the benchmark's: a 2048x2048 mosaic of four diagrams, a 1536x2560 image and a 1100x1700 colour one: every
+    plane, circle, line and record against the oracle."""
     a, b2 = synth.synth_diagram(11)[0], synth.synth_diagram(12)[0]
     big = np.ascontiguousarray(np.block([[a, b2], [b2[::-1], a[:, ::-1]]]))
-    wide = np.ascontiguousarray(np.pad(big, ((0, 0), (0, 512)), constant_values=255)[:1536])      # stays below the 4096-circle capacity
+    wide = np.ascontiguousarray(np.pad(big, ((0, 0), (0, 512)), constant_values=255)[:1536])
     sub = wide[:1100, :1700]
     col = np.ascontiguousarray(np.stack([sub, sub[:, ::-1], sub], axis=-1))
     det = Detector(0, 3, 2560, 2048)
     parity.run_and_compare(det, [big, wide, col])
     det.close()
+
+
+def test_capacity_grows_with_the_context_area():
+    """4096 small rings on a 16-pixel pitch: two of the ten HoughCircles calls return ~3840 circles each, 7690 in all -- more
+    than round 1's fixed lists (2048 per call, 4096 per image) could hold.  The reference's lists are unbounded
+    (img2sgf.py:179-186); here the capacities grow with the area the context was created for: the image overflows a 1024 x 1024
+    context (one unit per started megapixel; reported as I2S_ST_CAPACITY, never truncated) and completes, equal to the oracle in
+    every plane, circle and record, in a 2048 x 2048 context."""
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    d2 = (yy - ((yy // 16) * 16 + 8)) ** 2 + (xx - ((xx // 16) * 16 + 8)) ** 2
+    img = np.where((d2 <= 36) & (d2 >= 16), 0, 255).astype(np.uint8)
+    small = Detector(0, 1, 1024, 1024)
+    d_small = small.detect_batch([img])[0]
+    small.close()
+    assert d_small.status == 100 and not d_small.board_ready
+    large = Detector(0, 1, 2048, 2048)
+    d = parity.run_and_compare(large, [img])[0]
+    large.close()
+    assert d.status != 100 and len(d.circles_all) > 4096 and max(d.n_per_slot) > 2048
 
 
 def _blur_planes_match(det, imgs):
