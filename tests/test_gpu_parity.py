@@ -187,13 +187,24 @@ def test_bench_under_torchrun_single_rank():
 
 
 def test_capacity_overflow_is_reported_not_truncated():
-    """More Hough-line peaks than I2S_MAX_LINES: the image must come back with status CAPACITY, never silently cut."""
+    """Noise with a Hough-lines threshold of 1: thousands of circles and line peaks.  Whatever the oracle says exceeds a
+    capacity of include/i2s.h must come back as I2S_ST_CAPACITY (never silently cut); otherwise the record equals the oracle's."""
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (1024, 1024), dtype=np.uint8)
     det = Detector(0, 1, 1024, 1024)
     d = det.detect_batch([img], Params(line_threshold=1))[0]
-    assert d.status == 100 and not d.board_ready and d.sgf is None
     det.close()
+    ref = opipe.process_image(img, threshold=1, keep_planes=True)
+    dbg = [cvo.hough_circles(b, debug=True)[1] for b in ref["blurs"]]
+    over = (len(ref["circles_all"]) > 16384 or max(len(c) for c in ref["circles_per_variant"]) > 2048
+            or max(len(x["est"]) for x in dbg) > 4096 or max(x["n_centers"] for x in dbg) > 1024 * 1024 // 8
+            or len(ref["hlines"]) > 1024 or len(ref["vlines"]) > 1024)
+    if over:
+        assert d.status == 100 and not d.board_ready and d.sgf is None
+    else:
+        assert d.status != 100
+        parity.compare_detection(d, ref)
+    # a context one unit too small for a crowded image reports it: see test_capacity_grows_with_the_context_area
 
 
 def test_hysteresis_pass_budget_growth():
