@@ -494,10 +494,14 @@ __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ des
 // for a 0 bit, need drops by c.  All bookkeeping is sign-mask arithmetic on sub / shift-right / and / xor -- the full-rate
 // instructions of this chip (profiles/r02_a_valu_rate_*.txt) -- instead of compares and selects (half rate); the only
 // half-rate instructions left in a round are the two popcounts.  Exact for any input.
+// Content adaptivity (exact, see med_repeat): bit planes that are identical to the next higher plane over the whole tile are
+// neither kept in the ring nor given a round.  Line art -- a diagram of pure black and white, a scan after the reference's
+// contrast step -- has ONE distinct plane and costs a round instead of eight; a noisy photograph has eight and costs what
+// it did (DESIGN.md quotes both).
 constexpr int MT_W = 56, MT_H = 72, M_RPT = 8;
 constexpr int M_ROWS = MT_H + 6, M_SSTR = 17;
 
-struct MedState { unsigned alo, ahi; int need; unsigned r; };
+struct MedState { unsigned alo, ahi; int need; unsigned r; int nm; };
 
 // one bit-plane round for one (pixel, window): plo / phi = the plane's ring words
 __device__ __forceinline__ void med_round(MedState& s, unsigned plo, unsigned phi)
@@ -512,24 +516,33 @@ __device__ __forceinline__ void med_round(MedState& s, unsigned plo, unsigned ph
     s.ahi &= phi ^ (unsigned)nm;
     s.need -= c & nm;                                  // bit 0: the c candidates with a 1 are larger than the median
     s.r = s.r + s.r - (unsigned)nm;                    // collects the COMPLEMENT of the median, MSB first
+    s.nm = nm;
 }
+
+// A plane that equals the previously processed (next higher) plane over the whole tile needs no round: after that round all
+// candidates agree in the higher bit, hence in this one; c is then |candidates| or 0, and 1 <= need <= |candidates| always
+// holds, so the median's bit repeats the previous one and neither the candidates nor `need` change.
+__device__ __forceinline__ void med_repeat(MedState& s) { s.r = s.r + s.r - (unsigned)s.nm; }
 
 __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
                                                   uint8_t* __restrict__ out5, uint8_t* __restrict__ out7, int gx, int gy)
 {
     __shared__ unsigned s_src[M_ROWS * M_SSTR];
     __shared__ unsigned long long s_pl[8 * M_ROWS];
+    __shared__ unsigned s_differs;                   // bit p: plane p differs from plane p + 1 somewhere in the tile
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z;
     const int w = desc[b].w, h = desc[b].h;
     const int x0 = tl.tx * MT_W, y0 = tl.ty * MT_H;
     if (x0 >= w || y0 >= h) return;
     const int tid = threadIdx.x;
+    if (tid == 0) s_differs = 0;
     load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, desc[b].grey, desc[b].gpitch, w, h, x0 - 4, y0 - 3, tid);
     __syncthreads();
     {
         // 8 pixels -> 8 plane bytes (8x8 bit-matrix transpose: output byte p = plane p, bit i = pixel i)
         uint8_t* plb = reinterpret_cast<uint8_t*>(s_pl);
+        unsigned long long dacc = 0;                 // byte p: where plane p and plane p + 1 differ (over this thread's items)
         for (int i = tid; i < M_ROWS * 8; i += 256) {
             const int r = i >> 3, gq = i & 7;
             unsigned long long x = (unsigned long long)s_src[r * M_SSTR + 2 * gq] | ((unsigned long long)s_src[r * M_SSTR + 2 * gq + 1] << 32);
@@ -539,9 +552,16 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
             t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
 #pragma unroll
             for (int p = 0; p < 8; p++) plb[((size_t)p * M_ROWS + r) * 8 + gq] = (uint8_t)(x >> (8 * p));
+            dacc |= x ^ (x >> 8);
         }
+        unsigned diff = 0;
+#pragma unroll
+        for (int p = 0; p < 7; p++) diff |= ((dacc >> (8 * p)) & 0xffull) ? (1u << p) : 0u;
+        if (diff) atomicOr(&s_differs, diff);
     }
     __syncthreads();
+    // planes that get a ring and a round: plane 7 and every plane that differs from its upper neighbour (block-uniform)
+    const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_differs | 0x80u));
     if (tid >= 28 * 9) return;
     const int cg = tid % 28, rg = tid / 28;
     const int c = 2 * cg, r0 = rg * M_RPT;           // first tile column / output row of this thread
@@ -559,6 +579,7 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
         const int slot = t % 7;
 #pragma unroll
         for (int p = 0; p < 8; p++) {
+            if (!((live >> p) & 1u)) continue;
             const unsigned seg = (unsigned)(s_pl[p * M_ROWS + r0 + t] >> pos);                 // byte 0 = columns c-3 .. c+4
             if (slot < 4) rlo[p] = __builtin_amdgcn_perm(seg, rlo[p], SEL[slot]);
             else rhi[p] = __builtin_amdgcn_perm(seg, rhi[p], SEL[slot - 4]);
@@ -573,14 +594,18 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
                     if (o < 4) rows5lo &= ~(0xffu << (8 * o)); else rows5hi &= ~(0xffu << (8 * (o - 4)));
                     if (nw < 4) rows5lo &= ~(0xffu << (8 * nw)); else rows5hi &= ~(0xffu << (8 * (nw - 4)));
                 }
-                MedState m7a = {0x7f7f7f7fu, 0x007f7f7fu, 25, 0}, m7b = {0xfefefefeu, 0x00fefefeu, 25, 0};
-                MedState m5a = {0x3e3e3e3eu & rows5lo, 0x3e3e3e3eu & rows5hi, 13, 0}, m5b = {0x7c7c7c7cu & rows5lo, 0x7c7c7c7cu & rows5hi, 13, 0};
+                MedState m7a = {0x7f7f7f7fu, 0x007f7f7fu, 25, 0, 0}, m7b = {0xfefefefeu, 0x00fefefeu, 25, 0, 0};
+                MedState m5a = {0x3e3e3e3eu & rows5lo, 0x3e3e3e3eu & rows5hi, 13, 0, 0}, m5b = {0x7c7c7c7cu & rows5lo, 0x7c7c7c7cu & rows5hi, 13, 0, 0};
 #pragma unroll
                 for (int bit = 7; bit >= 0; bit--) {
-                    med_round(m7a, rlo[bit], rhi[bit]);
-                    med_round(m7b, rlo[bit], rhi[bit]);
-                    med_round(m5a, rlo[bit], rhi[bit]);
-                    med_round(m5b, rlo[bit], rhi[bit]);
+                    if ((live >> bit) & 1u) {
+                        med_round(m7a, rlo[bit], rhi[bit]);
+                        med_round(m7b, rlo[bit], rhi[bit]);
+                        med_round(m5a, rlo[bit], rhi[bit]);
+                        med_round(m5b, rlo[bit], rhi[bit]);
+                    } else {
+                        med_repeat(m7a); med_repeat(m7b); med_repeat(m5a); med_repeat(m5b);
+                    }
                 }
                 const unsigned v7 = ((m7a.r ^ 0xffu) & 0xffu) | (((m7b.r ^ 0xffu) & 0xffu) << 8);
                 const unsigned v5 = ((m5a.r ^ 0xffu) & 0xffu) | (((m5b.r ^ 0xffu) & 0xffu) << 8);

@@ -103,6 +103,8 @@ static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return 
 template <class T> static inline T __shfl_xor(T v, int m) { return __shfl(v, hipemu::cur->lane ^ m); }
 // wave-uniform lane select (v_readlane_b32): all live lanes call it with the same lane index
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
+// value of the first live lane; the callers pass wave-uniform values, for which this is the identity (and safe after lanes left)
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // wave-level barrier: on hardware only a scheduling barrier (a wave runs in lockstep); here all live lanes rendezvous
 static inline void __builtin_amdgcn_wave_barrier() { unsigned long long a[64], m; hipemu::wave_exchange(0, a, &m); }
 static inline int __lane_id() { return hipemu::cur->lane; }

@@ -252,6 +252,16 @@ def test_blur_bank_shapes_emulated(lib):
             for name, kk in (("median3", 3), ("median5", 5), ("median7", 7)):
                 np.testing.assert_array_equal(det.fetch_plane(i, name), cvo.median_blur(im, kk), err_msg="%s %s" % (name, im.shape))
             np.testing.assert_array_equal(det.fetch_plane(i, "grey"), im)
+    # few grey levels: bit planes that repeat their upper neighbour are skipped by the bit-serial medians (med_repeat)
+    levels = [(0, 255), (0, 128, 255), (0, 64, 192, 255), (17, 17), (0xF0, 0x0F, 0xFF, 0x00), (1, 2, 3)]
+    for lv in levels:
+        im = np.array(lv, np.uint8)[rng.integers(0, len(lv), (41, 60))]
+        det.detect_batch([im], full=False)
+        for name, kk in (("median3", 3), ("median5", 5), ("median7", 7)):
+            np.testing.assert_array_equal(det.fetch_plane(0, name), cvo.median_blur(im, kk), err_msg="%s levels %s" % (name, lv))
+    im = (rng.integers(0, 256, (41, 60)) & 0xF0).astype(np.uint8)
+    det.detect_batch([im], full=False)
+    np.testing.assert_array_equal(det.fetch_plane(0, "median7"), cvo.median_blur(im, 7))
     det.detect_batch([np.full((20, 40), 255, np.uint8)], Params(gauss_kernel_mode=1), full=False)     # tap sums != 256: integer kernels
     np.testing.assert_array_equal(det.fetch_plane(0, "gauss7"), cvo.gaussian_blur(np.full((20, 40), 255, np.uint8), 7, 7, 1))
     det.close()

@@ -391,6 +391,13 @@ def test_blur_bank_shapes():
                 imgs.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
         _blur_planes_match(det, imgs)
     det.close()
+    # few grey levels: bit planes that repeat their upper neighbour are skipped by the bit-serial medians (med_repeat)
+    det = Detector(0, 4, 300, 200)
+    for lv in [(0, 255), (0, 128, 255), (0, 64, 192, 255), (17, 17), (0xF0, 0x0F, 0xFF, 0x00), (1, 2, 3), (254, 255)]:
+        ims = [np.array(lv, np.uint8)[rng.integers(0, len(lv), (h, w))] for (h, w) in ((200, 300), (77, 130), (9, 9), (150, 57))]
+        ims[1] = (ims[1] & 0xF0).astype(np.uint8)
+        _blur_planes_match(det, ims)
+    det.close()
     # saturated planes (the largest partial sums of the float Gaussians) and device-resident sources used in place
     import torch
     det = Detector(0, 2, 1024, 200)
