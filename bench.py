@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("I2S_BENCH_BATCH", 4096)), help="diagrams per rank per step")
-    ap.add_argument("--pass-size", type=int, default=int(os.environ.get("I2S_BENCH_PASS", 128)), help="diagrams per device pass")
+    ap.add_argument("--pass-size", type=int, default=int(os.environ.get("I2S_BENCH_PASS", 256)), help="diagrams per device pass")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("I2S_BENCH_STREAMS", 3)), help="HIP streams (contexts) per GPU")
     ap.add_argument("--roofline-images", type=int, default=256)
     ap.add_argument("--cpu-per-worker", type=int, default=8, help="diagrams per CPU worker process in the cpu_baseline leg")

@@ -10,6 +10,9 @@ namespace i2s {
 
 constexpr int CT_W = 64;   // NMS output tile
 constexpr int CT_H = 32;
+#ifndef NMS_FW
+#define NMS_FW 16   // strips per row of a wavefront's NMS footprint (16 = whole strip rows: measured equal to 16 x 16 pixel blocks, stores coalesce better)
+#endif
 constexpr int NMS_TPB = 4;  // consecutive tiles (along x) handled by one workgroup of k_sobel_nms_planes, software-pipelined
 // hysteresis works on the same 64 x 32 tiles.  Tiles that hold weak pixels are appended to a worklist by the NMS kernels:
 // wl[0] = count, wl[1 + i] = (m * nb + b) * g.tiles + ty * g.tw + tx; only those tiles are ever visited again.
@@ -221,8 +224,13 @@ __global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restr
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NCORE / 256; k++) {
-        const int ci = tid + k * 256;
-        const int ry = ci / (CT_W / 4) + 1, s = ci % (CT_W / 4) + 1;
+        // A wavefront's 64 strips form a compact NMS_FW x (64 / NMS_FW) block of strips (4 NMS_FW x 64 / NMS_FW pixels) rather
+        // than whole strip rows: the suppression below is skipped per strip, but a wavefront only saves the time when ALL its
+        // strips skip, and on line art a compact block lies between the lines far more often than a 64-pixel-wide band does.
+        constexpr int NMS_FH = 64 / NMS_FW, NMS_BX = (CT_W / 4) / NMS_FW;
+        const int fb = (tid >> 6) + 4 * k, fl = tid & 63;                 // footprint index / strip inside it
+        const int ry = (fb / NMS_BX) * NMS_FH + fl / NMS_FW + 1, s = (fb % NMS_BX) * NMS_FW + fl % NMS_FW + 1;
+        const int ci = (ry - 1) * (CT_W / 4) + (s - 1);
         const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
         if (gy >= h || gx0 >= w) continue;
         unsigned outw = 0x01010101u, outw0 = 0x01010101u;
