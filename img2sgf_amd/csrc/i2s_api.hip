@@ -21,6 +21,7 @@
 #include "k_filters.h"
 #include "k_grid.h"
 #include "jpeg_host.h"
+#include "k_canny_rows.h"
 #include "k_hough_circles.h"
 #include "k_jpeg.h"
 #include "k_preprocess.h"
@@ -428,17 +429,17 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                            plane_ptr(ctx, I2S_PLANE_MEDIAN7), mx, my);
         I2S_SEG(3);
-        const int ngx = cdiv(fx, NMS_TPB);                             // groups of NMS_TPB tiles along x
         // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
         // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
         const bool fused0 = has_c1 && p->canny_lo == hc_lo;
         I2S_SEG(4);
+        const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
         if (fused0)
-            hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
-                               p->hc_param1, p->canny_hi, 2, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
+            hipLaunchKernelGGL(k_sobel_nms_rows, dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
+                               p->hc_param1, p->canny_hi, 2, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
         else if (has_c1)
-            hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
-                               p->canny_lo, p->canny_hi, p->canny_hi, 1, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
+            hipLaunchKernelGGL(k_sobel_nms_rows, dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
+                               p->canny_lo, p->canny_hi, p->canny_hi, 1, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
         if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
         I2S_SEG(5);
         rc = run_hysteresis(ctx, 0, fx * fy * nb);
@@ -446,8 +447,8 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
         I2S_SEG(6);
         const int v_first = fused0 ? 1 : 0;
-        hipLaunchKernelGGL(k_sobel_nms_planes, dim3((unsigned)ngx * fy * nb * (NVAR - v_first)), b256, 0, st, ctx->d_desc, g, grey, map0,
-                           (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, 0, worklist(ctx, 1), worklist(ctx, 0), ngx, fy);
+        hipLaunchKernelGGL(k_sobel_nms_rows, dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, 0, st, ctx->d_desc, g, grey, map0,
+                           (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, 0, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
         I2S_SEG(7);
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;

@@ -1,0 +1,234 @@
+// Sobel + non-maximum suppression of single-channel planes, register-resident (round 2): the Canny of img2sgf.py:162 for grey
+// sources and the Canny inside every cv.HoughCircles call (:180), same arithmetic as k_sobel_nms_planes (k_canny.h, OpenCV
+// canny.cpp: Sobel 3x3 CV_16S with BORDER_REPLICATE, L1 magnitude, TG22 sectors, strict '>' thresholds), no LDS, no barrier.
+// A lane owns one dword column (4 pixels) and walks down CR_R output rows; a wavefront is 256 pixels of a row.  Per input
+// row: the neighbour dwords come from the adjacent lanes (DPP), the pixels become 16-bit pairs, the vertical sums / differences
+// of the 3-row ring give the gradients of the row above (two pixels per packed instruction), and once the magnitudes of three
+// rows exist the row between them is suppressed and written.  The magnitudes left and right of the lane's 4 pixels come from
+// the neighbour lanes; at the two ends of the wavefront -- where the neighbour pixel belongs to another wavefront -- lanes 0
+// and 63 compute that one extra magnitude themselves from the three columns around it (byte dot products).
+// Map values: 0 = weak candidate, 1 = no edge, 2 = edge.  Tiles (64 x 32) that hold weak pixels go to the hysteresis worklist.
+#pragma once
+#include "k_canny.h"
+#include "k_filters.h"
+
+namespace i2s {
+
+constexpr int CR_R = CT_H;       // output rows per wavefront = one row of hysteresis tiles (+4 apron rows of input)
+
+struct CrThr { unsigned lowp, highp, high0p; };
+
+// suppression of one pixel pair (two 16-bit lanes): cur = magnitudes, L / R / above / below and the four diagonals, gx / gy the
+// gradients.  Returns the map values (0 / 1 / 2 per 16-bit lane) for the thresholds (low, high) and (low, high0).
+__device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned r1, unsigned c0, unsigned c2, unsigned l0, unsigned r0,
+                                            unsigned l2, unsigned r2, unsigned gxp, unsigned gyp, const CrThr& th, unsigned& o, unsigned& om)
+{
+    const unsigned c_h = pk_gt(cur, l1) & ~pk_gt(r1, cur);
+    const unsigned c_v = pk_gt(cur, c0) & ~pk_gt(c2, cur);
+    // diagonal: signs differ -> (above right, below left), else (above left, below right)
+    const unsigned msk = pk_bits(pk_from(gxp ^ gyp) >> 15);
+    const unsigned c_d = pk_gt(cur, bsel(msk, r0, l0)) & pk_gt(cur, bsel(msk, l2, r2));
+    const v2u ax = pku_from(pk_bits(pk_abs(pk_from(gxp))));
+    const unsigned ay = pk_bits(pk_abs(pk_from(gyp)));
+    // |dy| 2^15 < |dx| 13573  <=>  |dy| <= q,  |dy| 2^15 > |dx| 79109  <=>  |dy| > 2 |dx| + q,  q = floor(|dx| 13573 / 2^15) (k_canny.h)
+    const v2u q = (ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7;
+    const unsigned s22 = ~pk_gt(ay, pku_bits(q));
+    const unsigned s67 = pk_gt(ay, pku_bits(ax + ax + q));
+    const unsigned keep = bsel(s22, c_h, bsel(s67, c_v, c_d));
+    const unsigned kept = keep & pk_gt(cur, th.lowp);
+    o = (kept & pk_gt(cur, th.highp) & 0x00020002u) | (~kept & 0x00010001u);
+    om = (kept & pk_gt(cur, th.high0p) & 0x00020002u) | (~kept & 0x00010001u);
+}
+
+// main_mode as in k_sobel_nms_planes: 0 = HoughCircles' Canny of variants v_first .. (plane v -> map 1 + v), 1 = main Canny of grey
+// sources (plane 0 -> map 0 + edge image, threshold high_main), 2 = both at once for the grey plane.
+// grid: ceil(w / 1024) x ceil(h / CR_R) x (nb * variants) workgroups of 4 wavefronts (4 consecutive 256-pixel column groups).
+__global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
+                                                        uint8_t* __restrict__ maps, uint8_t* __restrict__ edges, int v_first, int low,
+                                                        int high, int high_main, int main_mode, int* __restrict__ weak,
+                                                        int* __restrict__ weak_main, int gx, int gy)
+{
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z % g.nb;
+    const int v = main_mode ? 0 : v_first + tl.z / g.nb;
+    const ImgDesc im = desc[b];
+    if (main_mode == 1 && im.cn != 1) return;
+    const bool main_out = main_mode != 0 && im.cn == 1;            // writes map 0 + edges
+    if (main_mode == 1) high = high_main;
+    const int w = im.w, h = im.h;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cgp = tl.tx * 4 + wave;                              // 256-pixel column group
+    const int x0 = (cgp * 64 + lane) * 4;
+    const int y0 = tl.ty * CR_R;
+    if (cgp * 256 >= w || y0 >= h) return;
+    const bool active = x0 < w;
+    const uint8_t* plane = v == 0 ? im.grey : planes + ((size_t)v * g.nb + b) * g.slot;
+    const int sp = v == 0 ? im.gpitch : g.pitch;
+    const int m_first = main_mode == 1 ? 0 : 1 + v;
+    uint8_t* mp = maps + ((size_t)m_first * g.nb + b) * g.slot;
+    uint8_t* mp0 = (main_mode == 2 && main_out) ? maps + (size_t)b * g.slot : nullptr;
+    uint8_t* ep = main_out ? edges + (size_t)b * g.slot : nullptr;
+    CrThr th;
+    th.lowp = (unsigned)(iclamp(low, -1, 4095) & 0xffff) * 0x00010001u;
+    th.highp = (unsigned)(iclamp(high, -1, 4095) & 0xffff) * 0x00010001u;
+    th.high0p = (unsigned)(iclamp(high_main, -1, 4095) & 0xffff) * 0x00010001u;
+
+    // BORDER_REPLICATE along x: byte k of the (L, M, R) triple is pixel x0 - 4 + k; lanes whose 3 x 4 bytes reach outside the
+    // image rebuild the triple with byte permutes (selectors computed once)
+    const bool fix_lane = active && (x0 - 4 < 0 || x0 + 7 >= w);
+    const bool fix = __any(fix_lane ? 1 : 0) != 0;
+    unsigned sL = 0x03020100u, sM = 0x07060504u, sR = 0x07060504u;      // L' = perm(M, L), M' = perm(M, L), R' = perm(R, M)
+    if (fix_lane) {
+        sL = 0; sM = 0; sR = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int l = iclamp(x0 - 4 + j, 0, w - 1) - (x0 - 4), m = iclamp(x0 + j, 0, w - 1) - (x0 - 4);
+            const int r = iclamp(x0 + 4 + j, 0, w - 1) - x0;                       // index into (M, R)
+            sL |= (unsigned)iclamp(l, 0, 7) << (8 * j);
+            sM |= (unsigned)iclamp(m, 0, 7) << (8 * j);
+            sR |= (unsigned)iclamp(r, 0, 7) << (8 * j);
+        }
+    }
+    // columns that exist in the image: gradients (hence magnitudes) outside are 0
+    const unsigned k01 = (x0 < w ? 0x0000ffffu : 0u) | (x0 + 1 < w ? 0xffff0000u : 0u);
+    const unsigned k23 = (x0 + 2 < w ? 0x0000ffffu : 0u) | (x0 + 3 < w ? 0xffff0000u : 0u);
+    // the extra magnitude of the wavefront's end lanes: column xe = x0 - 1 (lane 0) or x0 + 4 (lane 63)
+    const bool e_hi = lane == 63;
+    const int xe = e_hi ? x0 + 4 : x0 - 1;
+    const bool e_ok = (lane == 0 || lane == 63) && xe >= 0 && xe < w;
+    const unsigned eS = e_hi ? 0x0c050403u : 0x0c040302u;              // bytes (xe - 1, xe, xe + 1) of perm(hi, lo): lane 63: (M, R) -> M.b3, R.b0, R.b1 ; lane 0: (L, M) -> L.b2, L.b3, M.b0
+    unsigned vm = 0;                                                    // bytes of the output dword that are pixels of the image
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (x0 + q < w) vm |= 0xffu << (8 * q);
+
+    const bool has_e = (lane == 0 && x0 >= 4) || (lane == 63 && x0 + 4 < w);
+    const unsigned xm = active ? (unsigned)x0 : 0u, xeo = has_e ? (unsigned)(lane == 0 ? x0 - 4 : x0 + 4) : 0u;
+
+    unsigned PA[3], PB[3], PC[3], PE[3];            // pixel pairs (-1,0), (1,2), (3,4) and the end-lane bytes of the last 3 input rows
+    unsigned M01[3], M23[3], ML[3], MR[3];          // magnitudes of the last 3 gradient rows: own pairs, left pair of lane - 1, right pair of lane + 1
+    unsigned GX01[2], GX23[2], GY01[2], GY23[2];    // gradients of the last 2 gradient rows
+#pragma unroll
+    for (int i = 0; i < 3; i++) { PA[i] = PB[i] = PC[i] = PE[i] = 0; M01[i] = M23[i] = ML[i] = MR[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < 2; i++) { GX01[i] = GX23[i] = GY01[i] = GY23[i] = 0; }
+
+    unsigned nM, nE;
+    {
+        const uint8_t* rp = plane + rowoff(iclamp(y0 - 2, 0, h - 1), sp);
+        nM = bl_load(rp, xm);
+        nE = bl_load(rp, xeo);
+    }
+    unsigned wk_acc = 0, wk0_acc = 0;
+    static_assert((CR_R + 4) % 6 == 0, "the row loop is unrolled by the ring depths (3 and 2)");
+    const int t_end = imin(CR_R + 4, h + 2 - (y0 - 2));               // input rows beyond h + 1 feed no output of this band
+    for (int t0 = 0; t0 < t_end; t0 += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            const int t = t0 + u;
+            const int yi = y0 - 2 + t;                                 // input row (clamped when outside)
+            const unsigned M = nM, E = nE;
+            {
+                const uint8_t* rp = plane + rowoff(iclamp(yi + 1, 0, h - 1), sp);
+                nM = bl_load(rp, xm);
+                nE = bl_load(rp, xeo);
+            }
+            const unsigned up = bl_from_prev_lane(M), dn = bl_from_next_lane(M);
+            unsigned L = lane == 0 ? E : up, R = lane == 63 ? E : dn, Mf = M;
+            if (fix) {
+                const unsigned l2 = __builtin_amdgcn_perm(M, L, sL), m2 = __builtin_amdgcn_perm(M, L, sM), r2 = __builtin_amdgcn_perm(R, M, sR);
+                L = l2; Mf = m2; R = r2;
+            }
+            const int ps = u % 3;                                      // ring slot of this input row
+            PA[ps] = __builtin_amdgcn_perm(Mf, L, 0x0c040c03u);
+            PB[ps] = __builtin_amdgcn_perm(Mf, Mf, 0x0c020c01u);
+            PC[ps] = __builtin_amdgcn_perm(R, Mf, 0x0c040c03u);
+            PE[ps] = __builtin_amdgcn_perm(e_hi ? R : Mf, e_hi ? Mf : L, eS);
+            // gradient row yg = yi - 1 from input rows yi - 2, yi - 1, yi (slots ps + 1, ps + 2, ps)
+            const int yg = yi - 1;
+            const int gs = u % 3;                                      // magnitude ring slot of gradient row yg (same phase as ps)
+            const int g2 = u % 2;                                      // gradient ring slot
+            if (t >= 2) {
+                const int top = (u + 1) % 3, mid = (u + 2) % 3, bot = ps;
+                unsigned dx01 = 0, dx23 = 0, dy01 = 0, dy23 = 0, mg01 = 0, mg23 = 0, mge = 0;
+                if (yg >= 0 && yg < h) {
+                    const v2s ta = pk_from(PA[top]), tb = pk_from(PB[top]), tc = pk_from(PC[top]);
+                    const v2s ma = pk_from(PA[mid]), mb = pk_from(PB[mid]), mc = pk_from(PC[mid]);
+                    const v2s ba = pk_from(PA[bot]), bb = pk_from(PB[bot]), bc = pk_from(PC[bot]);
+                    const v2s ca = ta + ma + ma + ba, cb = tb + mb + mb + bb, cc = tc + mc + mc + bc;
+                    const v2s da = ba - ta, db = bb - tb, dc = bc - tc;
+                    const v2s x01 = cb - ca, x23 = cc - cb;
+                    const v2s m01 = pk_from(__builtin_amdgcn_alignbit(pk_bits(db), pk_bits(da), 16));    // (dif0, dif1)
+                    const v2s m23 = pk_from(__builtin_amdgcn_alignbit(pk_bits(dc), pk_bits(db), 16));    // (dif2, dif3)
+                    const v2s y01 = da + m01 + m01 + db, y23 = db + m23 + m23 + dc;
+                    dx01 = pk_bits(x01) & k01; dy01 = pk_bits(y01) & k01;
+                    dx23 = pk_bits(x23) & k23; dy23 = pk_bits(y23) & k23;
+                    mg01 = pk_bits(pk_abs(pk_from(dx01)) + pk_abs(pk_from(dy01)));
+                    mg23 = pk_bits(pk_abs(pk_from(dx23)) + pk_abs(pk_from(dy23)));
+                    // end lanes: magnitude at column xe from bytes (xe - 1, xe, xe + 1) of the three rows
+                    const unsigned et = PE[top], em = PE[mid], eb = PE[bot];
+                    const int sc = (int)__builtin_amdgcn_udot4(et, 0x00010000u, __builtin_amdgcn_udot4(em, 0x00020000u, __builtin_amdgcn_udot4(eb, 0x00010000u, 0u, false), false), false);
+                    const int sa = (int)__builtin_amdgcn_udot4(et, 0x00000001u, __builtin_amdgcn_udot4(em, 0x00000002u, __builtin_amdgcn_udot4(eb, 0x00000001u, 0u, false), false), false);
+                    const int edy = (int)__builtin_amdgcn_udot4(eb, 0x00010201u, 0u, false) - (int)__builtin_amdgcn_udot4(et, 0x00010201u, 0u, false);
+                    mge = e_ok ? (unsigned)(iabs_(sc - sa) + iabs_(edy)) : 0u;
+                }
+                GX01[g2] = dx01; GX23[g2] = dx23; GY01[g2] = dy01; GY23[g2] = dy23;
+                M01[gs] = mg01; M23[gs] = mg23;
+                // pair (x0 - 2, x0 - 1) of the left neighbour and pair (x0 + 4, x0 + 5) of the right one (only their inner halves are used)
+                const unsigned fl = bl_from_prev_lane(mg23), fr = bl_from_next_lane(mg01);
+                ML[gs] = lane == 0 ? (mge << 16) : fl;
+                MR[gs] = lane == 63 ? mge : fr;
+            }
+            // suppression of row yn = yg - 1 (magnitude rows yn - 1, yn, yn + 1 = slots gs + 1, gs + 2, gs; gradients in slot g2 ^ 1)
+            const int yn = yi - 2;
+            unsigned outw = 0x01010101u, outw0 = 0x01010101u;
+            const bool emit = t >= 4 && yn < h;
+            if (emit) {
+                const int ra = (u + 1) % 3, rc = (u + 2) % 3, rb = gs, gq = g2 ^ 1;
+                const unsigned mb01 = M01[rc], mb23 = M23[rc];
+                const int mxall = imax(imax((int)(mb01 & 0xffffu), (int)(mb01 >> 16)), imax((int)(mb23 & 0xffffu), (int)(mb23 >> 16)));
+                if (__any(mxall > low ? 1 : 0)) {
+                    unsigned Lr[3][2], Cr[3][2], Rr[3][2];
+                    const int rows[3] = {ra, rc, rb};
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++) {
+                        const unsigned a = ML[rows[rr]], b0 = M01[rows[rr]], b1 = M23[rows[rr]], c = MR[rows[rr]];
+                        Cr[rr][0] = b0; Cr[rr][1] = b1;
+                        Lr[rr][0] = __builtin_amdgcn_alignbit(b0, a, 16);
+                        Rr[rr][0] = Lr[rr][1] = __builtin_amdgcn_alignbit(b1, b0, 16);
+                        Rr[rr][1] = __builtin_amdgcn_alignbit(c, b1, 16);
+                    }
+                    unsigned o0, o0m, o1, o1m;
+                    cr_nms_pair(Cr[1][0], Lr[1][0], Rr[1][0], Cr[0][0], Cr[2][0], Lr[0][0], Rr[0][0], Lr[2][0], Rr[2][0], GX01[gq], GY01[gq], th, o0, o0m);
+                    cr_nms_pair(Cr[1][1], Lr[1][1], Rr[1][1], Cr[0][1], Cr[2][1], Lr[0][1], Rr[0][1], Lr[2][1], Rr[2][1], GX23[gq], GY23[gq], th, o1, o1m);
+                    outw = __builtin_amdgcn_perm(o1, o0, 0x06040200u);
+                    outw0 = __builtin_amdgcn_perm(o1m, o0m, 0x06040200u);
+                }
+                outw = (outw & vm) | (0x01010101u & ~vm);
+                outw0 = (outw0 & vm) | (0x01010101u & ~vm);
+                wk_acc |= (outw - 0x01010101u) & ~outw & 0x80808080u;            // some byte == 0
+                wk0_acc |= (outw0 - 0x01010101u) & ~outw0 & 0x80808080u;
+            }
+            // stores after the wait for the prefetched row (see BL_CONSUME in k_filters.h)
+            BL_SCHED_FENCE();
+            BL_CONSUME(nM, nE);
+            BL_SCHED_FENCE();
+            if (emit && active) {
+                const int off = rowoff(yn, g.pitch);
+                bl_store(mp + off, xm, outw);
+                if (mp0) bl_store(mp0 + off, xm, outw0);
+                if (ep) { const unsigned outm = mp0 ? outw0 : outw; bl_store(ep + off, xm, ((outm >> 1) & 0x01010101u) * 0xffu); }
+            }
+        }
+    }
+    // hysteresis worklist: one key per 64 x 32 tile (16 lanes) that holds a weak pixel
+    const unsigned long long bw = __ballot(wk_acc != 0u && active), bw0 = __ballot(mp0 != nullptr && wk0_acc != 0u && active);
+    if ((lane & 15) == 0) {
+        const int tile_x = cgp * 4 + (lane >> 4);
+        const unsigned long long grp = 0xffffull << lane;
+        int* weak_first = main_mode == 1 ? weak_main : weak;
+        if (bw & grp) weak_first[1 + atomicAdd(&weak_first[0], 1)] = (int)(((size_t)m_first * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x);
+        if (bw0 & grp) weak_main[1 + atomicAdd(&weak_main[0], 1)] = (int)((size_t)b * g.tiles + (size_t)tl.ty * g.tw + tile_x);
+    }
+}
+
+}  // namespace i2s
