@@ -14,7 +14,7 @@
 
 namespace i2s {
 
-constexpr int CR_R = CT_H;       // output rows per wavefront = one row of hysteresis tiles (+4 apron rows of input)
+constexpr int CR_R = CT_H;       // output rows per wavefront = one row of hysteresis tiles (+4 apron rows of input; 4 x CT_H measured: no faster)
 
 struct CrThr { unsigned lowp, highp, high0p; };
 
@@ -132,8 +132,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                 nM = bl_load(rp, xm);
                 nE = bl_load(rp, xeo);
             }
-            const unsigned up = bl_from_prev_lane(M), dn = bl_from_next_lane(M);
-            unsigned L = lane == 0 ? E : up, R = lane == 63 ? E : dn, Mf = M;
+            unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E), Mf = M;
             if (fix) {
                 const unsigned l2 = __builtin_amdgcn_perm(M, L, sL), m2 = __builtin_amdgcn_perm(M, L, sM), r2 = __builtin_amdgcn_perm(R, M, sR);
                 L = l2; Mf = m2; R = r2;
@@ -174,9 +173,8 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                 GX01[g2] = dx01; GX23[g2] = dx23; GY01[g2] = dy01; GY23[g2] = dy23;
                 M01[gs] = mg01; M23[gs] = mg23;
                 // pair (x0 - 2, x0 - 1) of the left neighbour and pair (x0 + 4, x0 + 5) of the right one (only their inner halves are used)
-                const unsigned fl = bl_from_prev_lane(mg23), fr = bl_from_next_lane(mg01);
-                ML[gs] = lane == 0 ? (mge << 16) : fl;
-                MR[gs] = lane == 63 ? mge : fr;
+                ML[gs] = bl_from_prev_lane(mg23, mge << 16);
+                MR[gs] = bl_from_next_lane(mg01, mge);
             }
             // suppression of row yn = yg - 1 (magnitude rows yn - 1, yn, yn + 1 = slots gs + 1, gs + 2, gs; gradients in slot g2 ^ 1)
             const int yn = yi - 2;
@@ -218,16 +216,19 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                 if (mp0) bl_store(mp0 + off, xm, outw0);
                 if (ep) { const unsigned outm = mp0 ? outw0 : outw; bl_store(ep + off, xm, ((outm >> 1) & 0x01010101u) * 0xffu); }
             }
+            // hysteresis worklist: at the last row of a row of 64 x 32 tiles, one key per tile (16 lanes) that holds a weak pixel
+            if (emit && ((yn & (CT_H - 1)) == CT_H - 1 || yn == h - 1)) {
+                const unsigned long long bw = __ballot(wk_acc != 0u && active), bw0 = __ballot(mp0 != nullptr && wk0_acc != 0u && active);
+                if ((lane & 15) == 0) {
+                    const int tile_x = cgp * 4 + (lane >> 4), tile_y = yn / CT_H;
+                    const unsigned long long grp = 0xffffull << lane;
+                    int* weak_first = main_mode == 1 ? weak_main : weak;
+                    if (bw & grp) weak_first[1 + atomicAdd(&weak_first[0], 1)] = (int)(((size_t)m_first * g.nb + b) * g.tiles + (size_t)tile_y * g.tw + tile_x);
+                    if (bw0 & grp) weak_main[1 + atomicAdd(&weak_main[0], 1)] = (int)((size_t)b * g.tiles + (size_t)tile_y * g.tw + tile_x);
+                }
+                wk_acc = 0; wk0_acc = 0;
+            }
         }
-    }
-    // hysteresis worklist: one key per 64 x 32 tile (16 lanes) that holds a weak pixel
-    const unsigned long long bw = __ballot(wk_acc != 0u && active), bw0 = __ballot(mp0 != nullptr && wk0_acc != 0u && active);
-    if ((lane & 15) == 0) {
-        const int tile_x = cgp * 4 + (lane >> 4);
-        const unsigned long long grp = 0xffffull << lane;
-        int* weak_first = main_mode == 1 ? weak_main : weak;
-        if (bw & grp) weak_first[1 + atomicAdd(&weak_first[0], 1)] = (int)(((size_t)m_first * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x);
-        if (bw0 & grp) weak_main[1 + atomicAdd(&weak_main[0], 1)] = (int)((size_t)b * g.tiles + (size_t)tl.ty * g.tw + tile_x);
     }
 }
 

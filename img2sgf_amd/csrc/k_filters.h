@@ -184,13 +184,15 @@ template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v)
 // Loads go through the global address space with a uniform base + 32-bit lane offset (the pointer comes out of the
 // descriptor table, so the compiler would otherwise issue FLAT loads, which also wait on the LDS counter).
 #ifdef HIPEMU
-__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v) { return (unsigned)__shfl_up((int)v, 1); }
-__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v) { return (unsigned)__shfl_down((int)v, 1); }
+// value of lane - 1 / lane + 1; lane 0 / lane 63, which have no such neighbour, get `fill`
+__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v, unsigned fill) { const unsigned u = (unsigned)__shfl_up((int)v, 1); return __lane_id() == 0 ? fill : u; }
+__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v, unsigned fill) { const unsigned u = (unsigned)__shfl_down((int)v, 1); return __lane_id() == 63 ? fill : u; }
 __device__ __forceinline__ unsigned bl_load(const uint8_t* base, unsigned off) { return *reinterpret_cast<const unsigned*>(base + off); }
 __device__ __forceinline__ void bl_store(uint8_t* base, unsigned off, unsigned v) { *reinterpret_cast<unsigned*>(base + off) = v; }
 #else
-__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
-__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+// DPP whole-wave shifts; the lane without a source keeps the `old` operand (bound_ctrl off), i.e. `fill`, at no extra cost
+__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v, unsigned fill) { return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v, unsigned fill) { return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
 __device__ __forceinline__ unsigned bl_load(const uint8_t* base, unsigned off)
 {
     return *reinterpret_cast<const __attribute__((address_space(1))) unsigned*>(
@@ -328,8 +330,7 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
     if (y0 == 0) {
         // BORDER_REPLICATE above the image: the ring starts out holding row 0 as "row -1"
         const unsigned M = bl_load(src, xm), E = bl_load(src, xe);
-        const unsigned up = bl_from_prev_lane(M), dn = bl_from_next_lane(M);
-        bl_median_pixels(lane == 0 ? E : up, M, lane == 63 ? E : dn, fix, mS, F1);
+        bl_median_pixels(bl_from_prev_lane(M, E), M, bl_from_next_lane(M, E), fix, mS, F1);
     }
 
     // the loads of row t + 1 are in flight while row t is computed
@@ -359,8 +360,7 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
                 nM = bl_load(rp, xm);
                 nE = bl_load(rp, xe);
             }
-            const unsigned up = bl_from_prev_lane(M), dn = bl_from_next_lane(M);
-            const unsigned L = lane == 0 ? E : up, R = lane == 63 ? E : dn;
+            const unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E);
             unsigned gl = L, gm = M, gr = R;
             if (fix) {
                 gl = __builtin_amdgcn_perm(M, L, gA[0]);
