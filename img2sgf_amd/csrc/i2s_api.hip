@@ -87,7 +87,7 @@ struct i2s_ctx {
 // segments of i2s_last_kernel_timing, in launch order
 static const char* const kSegName[I2S_NSEG] = {
     "k_grey", "k_blur", "k_median57", "(unused)", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
-    "k_sobel_nms_planes(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
+    "k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
     "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
 #define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
 

@@ -10,10 +10,6 @@ namespace i2s {
 
 constexpr int CT_W = 64;   // NMS output tile
 constexpr int CT_H = 32;
-#ifndef NMS_FW
-#define NMS_FW 16   // strips per row of a wavefront's NMS footprint (16 = whole strip rows: measured equal to 16 x 16 pixel blocks, stores coalesce better)
-#endif
-constexpr int NMS_TPB = 4;  // consecutive tiles (along x) handled by one workgroup of k_sobel_nms_planes, software-pipelined
 // hysteresis works on the same 64 x 32 tiles.  Tiles that hold weak pixels are appended to a worklist by the NMS kernels:
 // wl[0] = count, wl[1 + i] = (m * nb + b) * g.tiles + ty * g.tw + tx; only those tiles are ever visited again.
 
@@ -106,7 +102,7 @@ __device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, i
     if (tid == 0 && s_weak) weak_wl[1 + atomicAdd(&weak_wl[0], 1)] = weak_key;
 }
 
-// Main Canny (map 0) on the source image: grid (tiles_x, tiles_y, nb).
+// Main Canny (map 0) on COLOUR source images (single-channel planes go through k_sobel_nms_rows, k_canny_rows.h): grid (tiles_x, tiles_y, nb).
 template <int CN>
 __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ map0,
                                                        uint8_t* __restrict__ edges, int low, int high, int* __restrict__ weak,
@@ -118,194 +114,6 @@ __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict
     if (im.cn != CN) return;
     sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, edges + (size_t)b * g.slot, g.pitch,
                        weak, (int)((size_t)b * g.tiles + (size_t)t.ty * g.tw + t.tx), t.tx, t.ty);
-}
-
-// Sobel + NMS on single-channel PLANES, 4 pixels per thread with dword LDS traffic.
-//   main_mode == 0: HoughCircles' internal Canny of variants [v_first, v_first + gridDim.z / nb): plane v -> map 1 + v.
-//   main_mode == 1: the main Canny (img2sgf.py:162) of greyscale sources: plane 0 (grey == source) -> map 0
-//                   (colour sources go through k_sobel_nms_src<3>); also writes the edge image (255 where the map says
-//                   "edge") into `edges`, which the map-0 hysteresis then completes.
-//   main_mode == 2: both at once for variant 0 (the grey plane): HoughCircles' Canny (low, high) -> map 1 and, for greyscale
-//                   sources, the main Canny (low, high_main) -> map 0 + edges.  Valid when both use the same low threshold
-//                   (the reference's 50 == 100 / 2): the gradients, sectors and suppression decisions are then shared and
-//                   only the strong / weak split differs.
-// grid (tiles_x, tiles_y, nb * nvariants), block 256, tile 64 x 32 outputs.
-// planes = variant plane 0 base, maps = map 0 base.
-__global__ __launch_bounds__(256) void k_sobel_nms_planes(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
-                                                          uint8_t* __restrict__ maps, uint8_t* __restrict__ edges, int v_first, int low,
-                                                          int high, int high_main, int main_mode, int* __restrict__ weak,
-                                                          int* __restrict__ weak_main, int gx, int gy)
-{
-    __shared__ int s_weak, s_weak0;
-    constexpr int SROWS = CT_H + 4, SWORDS = CT_W / 4 + 4, SSTR = SWORDS + 1;   // source rows y0-2.., x0-8 .. x0+72
-    constexpr int MROWS = CT_H + 2, MSTRIPS = CT_W / 4 + 2, MSTR = 2 * MSTRIPS + 1;   // mag rows y0-1.., x0-4 .. x0+68 (u16 pairs)
-    __shared__ unsigned s_src[SROWS * SSTR];
-    __shared__ unsigned s_mag[MROWS * MSTR];
-    __shared__ unsigned s_grad[CT_H * (CT_W / 4) * 4];      // dx01, dx23, dy01, dy23 of the core strips
-    // gx counts GROUPS of NMS_TPB tiles; the workgroup walks its group left to right and fetches tile t+1 into registers
-    // while it computes tile t (the tile kernels are otherwise latency-bound: load -> wait -> compute -> store)
-    const TileId tl = tile_of_block(gx, gy);
-    const int b = tl.z % g.nb;
-    const int v = main_mode ? 0 : v_first + tl.z / g.nb;
-    if (main_mode == 1 && desc[b].cn != 1) return;
-    const bool main_out = main_mode != 0 && desc[b].cn == 1;     // writes map 0 + edges
-    if (main_mode == 1) high = high_main;
-    const int w = desc[b].w, h = desc[b].h;
-    const int y0 = tl.ty * CT_H;
-    if (tl.tx * NMS_TPB * CT_W >= w || y0 >= h) return;
-    const int tid = threadIdx.x;
-    // variant 0 is the grey plane, which may be the source image itself (ImgDesc::grey)
-    const uint8_t* plane = v == 0 ? desc[b].grey : planes + ((size_t)v * g.nb + b) * g.slot;
-    const int ppitch = v == 0 ? desc[b].gpitch : g.pitch;
-    // first output: the variant's map (modes 0, 2) or map 0 (mode 1); second output (mode 2 only): map 0
-    const int m_first = main_mode == 1 ? 0 : 1 + v;
-    uint8_t* mp = maps + ((size_t)m_first * g.nb + b) * g.slot;
-    uint8_t* mp0 = (main_mode == 2 && main_out) ? maps + (size_t)b * g.slot : nullptr;
-    uint8_t* ep = main_out ? edges + (size_t)b * g.slot : nullptr;
-    int* weak_first = main_mode == 1 ? weak_main : weak;
-    TileRegs<SROWS, SWORDS, 256, BORDER_REPL> pre;
-    pre.fetch(plane, ppitch, w, h, tl.tx * NMS_TPB * CT_W - 8, y0 - 2, tid);
-    for (int tt = 0; tt < NMS_TPB; tt++) {
-    const int tile_x = tl.tx * NMS_TPB + tt;
-    const int x0 = tile_x * CT_W;
-    if (x0 >= w) break;
-    if (tid == 0) { s_weak = 0; s_weak0 = 0; }
-    pre.park<SSTR>(s_src, tid);
-    __syncthreads();
-    if (tt + 1 < NMS_TPB && x0 + CT_W < w) pre.fetch(plane, ppitch, w, h, x0 + CT_W - 8, y0 - 2, tid);
-    // gradient strips: strip (ry, s) covers pixels x = x0 - 4 + 4s .. +3 of image row y0 - 1 + ry.
-    // Two pixels per register (16-bit lanes, v_pk_* instructions): column sums / row differences of the 3x6
-    // neighbourhood, then dx = col[+1] - col[-1], dy = dif[-1] + 2 dif[0] + dif[+1], mag = |dx| + |dy|.
-    constexpr int NSTRIPS = MROWS * MSTRIPS;          // 34 * 18 = 612 gradient strips (core + apron)
-    constexpr int PER = (NSTRIPS + 255) / 256;        // 3
-    constexpr int NCORE = CT_H * (CT_W / 4);          // 512 core strips: exactly 2 per thread in the NMS phase
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int i = tid + k * 256;
-        if (i < NSTRIPS) {
-            const int ry = i / MSTRIPS, s = i - ry * MSTRIPS;
-            const unsigned* p0 = s_src + ry * SSTR + s;
-            v2s ra[3], rb[3], rc[3];          // pixel pairs (-1,0), (1,2), (3,4) of the three rows
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const unsigned a = p0[j * SSTR], b0 = p0[j * SSTR + 1], c = p0[j * SSTR + 2];
-                ra[j] = pk_from(__builtin_amdgcn_perm(b0, a, 0x0c040c03u));
-                rb[j] = pk_from(__builtin_amdgcn_perm(b0, b0, 0x0c020c01u));
-                rc[j] = pk_from(__builtin_amdgcn_perm(c, b0, 0x0c040c03u));
-            }
-            const v2s ca = ra[0] + ra[1] + ra[1] + ra[2], cb = rb[0] + rb[1] + rb[1] + rb[2], cc = rc[0] + rc[1] + rc[1] + rc[2];
-            const v2s da = ra[2] - ra[0], db = rb[2] - rb[0], dc = rc[2] - rc[0];
-            v2s dx01 = cb - ca, dx23 = cc - cb;
-            const v2s m01 = pk_from(__builtin_amdgcn_alignbit(pk_bits(db), pk_bits(da), 16));    // (dif0, dif1)
-            const v2s m23 = pk_from(__builtin_amdgcn_alignbit(pk_bits(dc), pk_bits(db), 16));    // (dif2, dif3)
-            v2s dy01 = da + m01 + m01 + db, dy23 = db + m23 + m23 + dc;
-            const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
-            if (gy < 0 || gy >= h || gx0 < 0 || gx0 + 3 >= w) {
-                // strip touches the image border: gradients (hence magnitudes) outside the image are 0
-                const bool row_ok = gy >= 0 && gy < h;
-                unsigned k01 = 0, k23 = 0;
-                if (row_ok && gx0 >= 0 && gx0 < w) k01 |= 0x0000ffffu;
-                if (row_ok && gx0 + 1 >= 0 && gx0 + 1 < w) k01 |= 0xffff0000u;
-                if (row_ok && gx0 + 2 >= 0 && gx0 + 2 < w) k23 |= 0x0000ffffu;
-                if (row_ok && gx0 + 3 >= 0 && gx0 + 3 < w) k23 |= 0xffff0000u;
-                dx01 = pk_from(pk_bits(dx01) & k01); dy01 = pk_from(pk_bits(dy01) & k01);
-                dx23 = pk_from(pk_bits(dx23) & k23); dy23 = pk_from(pk_bits(dy23) & k23);
-            }
-            const v2s mg01 = pk_abs(dx01) + pk_abs(dy01), mg23 = pk_abs(dx23) + pk_abs(dy23);
-            s_mag[ry * MSTR + 2 * s] = pk_bits(mg01);
-            s_mag[ry * MSTR + 2 * s + 1] = pk_bits(mg23);
-            if (ry >= 1 && ry <= CT_H && s >= 1 && s <= CT_W / 4) {
-                // core strip: park the gradient for the NMS phase, which is mapped densely onto the 512 core strips
-                unsigned* pg = s_grad + ((ry - 1) * (CT_W / 4) + (s - 1)) * 4;
-                pg[0] = pk_bits(dx01); pg[1] = pk_bits(dx23); pg[2] = pk_bits(dy01); pg[3] = pk_bits(dy23);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NCORE / 256; k++) {
-        // A wavefront's 64 strips form a compact NMS_FW x (64 / NMS_FW) block of strips (4 NMS_FW x 64 / NMS_FW pixels) rather
-        // than whole strip rows: the suppression below is skipped per strip, but a wavefront only saves the time when ALL its
-        // strips skip, and on line art a compact block lies between the lines far more often than a 64-pixel-wide band does.
-        constexpr int NMS_FH = 64 / NMS_FW, NMS_BX = (CT_W / 4) / NMS_FW;
-        const int fb = (tid >> 6) + 4 * k, fl = tid & 63;                 // footprint index / strip inside it
-        const int ry = (fb / NMS_BX) * NMS_FH + fl / NMS_FW + 1, s = (fb % NMS_BX) * NMS_FW + fl % NMS_FW + 1;
-        const int ci = (ry - 1) * (CT_W / 4) + (s - 1);
-        const int gy = y0 - 1 + ry, gx0 = x0 - 4 + 4 * s;
-        if (gy >= h || gx0 >= w) continue;
-        unsigned outw = 0x01010101u, outw0 = 0x01010101u;
-        const unsigned mb01 = s_mag[ry * MSTR + 2 * s], mb23 = s_mag[ry * MSTR + 2 * s + 1];
-        const int mxall = imax(imax((int)(mb01 & 0xffffu), (int)(mb01 >> 16)), imax((int)(mb23 & 0xffffu), (int)(mb23 >> 16)));
-        if (mxall > low) {
-            // Non-maximum suppression of the strip's 4 pixels as two pairs in 16-bit lanes (magnitudes <= 2040, gradients
-            // <= 1020): comparisons are packed subtractions whose sign is spread over the lane; the sector tests
-            // |dy| * 2^15 < |dx| * 13573 and |dy| * 2^15 > |dx| * 79109 become |dy| <= q and |dy| > 2 |dx| + q with
-            // q = floor(|dx| * 13573 / 2^15) = (|dx| * 53 + (|dx| * 5 >> 8)) >> 7 (13573 = 53 * 256 + 5 is odd, so the quotient
-            // is never exact for |dx| > 0, and for |dx| = |dy| = 0 the magnitude is 0 and nothing is kept anyway).
-            const unsigned* pg = s_grad + ci * 4;
-            unsigned L[3][2], C[3][2], R[3][2];       // per row (above, this, below) and pair: left / centre / right magnitudes
-#pragma unroll
-            for (int rr = 0; rr < 3; rr++) {
-                const unsigned* pm = s_mag + (ry - 1 + rr) * MSTR + 2 * s;
-                const unsigned a = pm[-1], b0 = pm[0], b1 = pm[1], c = pm[2];
-                C[rr][0] = b0; C[rr][1] = b1;
-                L[rr][0] = __builtin_amdgcn_alignbit(b0, a, 16);
-                R[rr][0] = L[rr][1] = __builtin_amdgcn_alignbit(b1, b0, 16);
-                R[rr][1] = __builtin_amdgcn_alignbit(c, b1, 16);
-            }
-            const unsigned lowp = (unsigned)(iclamp(low, -1, 4095) & 0xffff) * 0x00010001u;
-            const unsigned highp = (unsigned)(iclamp(high, -1, 4095) & 0xffff) * 0x00010001u;
-            const unsigned high0p = (unsigned)(iclamp(high_main, -1, 4095) & 0xffff) * 0x00010001u;
-            unsigned o16[2], o16m[2];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const unsigned cur = C[1][j];
-                const unsigned gxp = pg[j], gyp = pg[2 + j];
-                const unsigned c_h = pk_gt(cur, L[1][j]) & ~pk_gt(R[1][j], cur);
-                const unsigned c_v = pk_gt(cur, C[0][j]) & ~pk_gt(C[2][j], cur);
-                // diagonal: signs differ -> (above right, below left), else (above left, below right)
-                const unsigned msk = pk_bits(pk_from(gxp ^ gyp) >> 15);
-                const unsigned c_d = pk_gt(cur, bsel(msk, R[0][j], L[0][j])) & pk_gt(cur, bsel(msk, L[2][j], R[2][j]));
-                const v2u ax = pku_from(pk_bits(pk_abs(pk_from(gxp))));
-                const unsigned ay = pk_bits(pk_abs(pk_from(gyp)));
-                const v2u q = (ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7;
-                const unsigned s22 = ~pk_gt(ay, pku_bits(q));
-                const unsigned s67 = pk_gt(ay, pku_bits(ax + ax + q));
-                const unsigned keep = bsel(s22, c_h, bsel(s67, c_v, c_d));
-                const unsigned kept = keep & pk_gt(cur, lowp);
-                o16[j] = (kept & pk_gt(cur, highp) & 0x00020002u) | (~kept & 0x00010001u);
-                o16m[j] = (kept & pk_gt(cur, high0p) & 0x00020002u) | (~kept & 0x00010001u);
-            }
-            outw = __builtin_amdgcn_perm(o16[1], o16[0], 0x06040200u);
-            outw0 = __builtin_amdgcn_perm(o16m[1], o16m[0], 0x06040200u);
-        }
-        const int off = rowoff(gy, g.pitch) + gx0;
-        const unsigned outm = mp0 ? outw0 : outw;                        // the word that is the main Canny's map
-        const unsigned edgw = ((outm >> 1) & 0x01010101u) * 0xffu;       // 255 where that byte is 2
-        bool wk, wk0 = false;
-        if (gx0 + 3 < w) {
-            *reinterpret_cast<unsigned*>(mp + off) = outw;
-            if (mp0) *reinterpret_cast<unsigned*>(mp0 + off) = outw0;
-            if (ep) *reinterpret_cast<unsigned*>(ep + off) = edgw;
-            wk = ((outw - 0x01010101u) & ~outw & 0x80808080u) != 0;      // some byte == 0
-            if (mp0) wk0 = ((outw0 - 0x01010101u) & ~outw0 & 0x80808080u) != 0;
-        } else {
-            wk = false;
-            for (int q = 0; q < 4 && gx0 + q < w; q++) {
-                mp[off + q] = (uint8_t)(outw >> (8 * q)); wk |= ((outw >> (8 * q)) & 0xffu) == 0;
-                if (mp0) { mp0[off + q] = (uint8_t)(outw0 >> (8 * q)); wk0 |= ((outw0 >> (8 * q)) & 0xffu) == 0; }
-                if (ep) ep[off + q] = (uint8_t)(edgw >> (8 * q));
-            }
-        }
-        if (wk0) s_weak0 = 1;
-        if (wk) s_weak = 1;
-    }
-    __syncthreads();
-    if (tid == 0 && s_weak)
-        weak_first[1 + atomicAdd(&weak_first[0], 1)] = (int)(((size_t)m_first * g.nb + b) * g.tiles + (size_t)tl.ty * g.tw + tile_x);
-    if (tid == 0 && s_weak0)
-        weak_main[1 + atomicAdd(&weak_main[0], 1)] = (int)((size_t)b * g.tiles + (size_t)tl.ty * g.tw + tile_x);
-    }   // tiles of the group
 }
 
 // One hysteresis pass over the tiles of a worklist (all maps of the phase).  A fixed, small grid of workgroups strides over

@@ -1,5 +1,5 @@
 // Sobel + non-maximum suppression of single-channel planes, register-resident (round 2): the Canny of img2sgf.py:162 for grey
-// sources and the Canny inside every cv.HoughCircles call (:180), same arithmetic as k_sobel_nms_planes (k_canny.h, OpenCV
+// sources and the Canny inside every cv.HoughCircles call (:180), same arithmetic as round 1's LDS-tiled kernel (OpenCV
 // canny.cpp: Sobel 3x3 CV_16S with BORDER_REPLICATE, L1 magnitude, TG22 sectors, strict '>' thresholds), no LDS, no barrier.
 // A lane owns one dword column (4 pixels) and walks down CR_R output rows; a wavefront is 256 pixels of a row.  Per input
 // row: the neighbour dwords come from the adjacent lanes (DPP), the pixels become 16-bit pairs, the vertical sums / differences
@@ -30,7 +30,8 @@ __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned 
     const unsigned c_d = pk_gt(cur, bsel(msk, r0, l0)) & pk_gt(cur, bsel(msk, l2, r2));
     const v2u ax = pku_from(pk_bits(pk_abs(pk_from(gxp))));
     const unsigned ay = pk_bits(pk_abs(pk_from(gyp)));
-    // |dy| 2^15 < |dx| 13573  <=>  |dy| <= q,  |dy| 2^15 > |dx| 79109  <=>  |dy| > 2 |dx| + q,  q = floor(|dx| 13573 / 2^15) (k_canny.h)
+    // |dy| 2^15 < |dx| 13573  <=>  |dy| <= q,  |dy| 2^15 > |dx| 79109  <=>  |dy| > 2 |dx| + q,  q = floor(|dx| 13573 / 2^15) = (|dx| 53 + (|dx| 5 >> 8)) >> 7:
+    // 13573 = 53 * 256 + 5 is odd, so the quotient is never exact for |dx| > 0, and for |dx| = |dy| = 0 the magnitude is 0 and nothing is kept
     const v2u q = (ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7;
     const unsigned s22 = ~pk_gt(ay, pku_bits(q));
     const unsigned s67 = pk_gt(ay, pku_bits(ax + ax + q));
@@ -40,7 +41,7 @@ __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned 
     om = (kept & pk_gt(cur, th.high0p) & 0x00020002u) | (~kept & 0x00010001u);
 }
 
-// main_mode as in k_sobel_nms_planes: 0 = HoughCircles' Canny of variants v_first .. (plane v -> map 1 + v), 1 = main Canny of grey
+// main_mode: 0 = HoughCircles' Canny of variants v_first .. (plane v -> map 1 + v), 1 = main Canny of grey
 // sources (plane 0 -> map 0 + edge image, threshold high_main), 2 = both at once for the grey plane.
 // grid: ceil(w / 1024) x ceil(h / CR_R) x (nb * variants) workgroups of 4 wavefronts (4 consecutive 256-pixel column groups).
 __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,

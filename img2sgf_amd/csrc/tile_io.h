@@ -51,40 +51,6 @@ __device__ __forceinline__ void load_tile_words(unsigned* __restrict__ dst, cons
     }
 }
 
-// Split form for software pipelining: fetch the thread's share of a tile into registers now, park it in LDS later.
-template <int ROWS, int WORDS, int NT, int MODE>
-struct TileRegs {
-    static constexpr int PER = (ROWS * WORDS + NT - 1) / NT;
-    unsigned v[PER];
-    __device__ __forceinline__ void fetch(const uint8_t* __restrict__ plane, int pitch, int w, int h, int xa, int ya, int tid)
-    {
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int i = tid + k * NT;
-            unsigned val = 0;
-            if (i < ROWS * WORDS) {
-                const int r = i / WORDS, c = i - r * WORDS;
-                const int gy = border_idx<MODE>(ya + r, h);
-                const int x = xa + 4 * c;
-                const uint8_t* row = plane + rowoff(gy, pitch);
-                if (x >= 0 && x + 3 < w) val = *reinterpret_cast<const unsigned*>(row + x);
-                else val = (unsigned)row[border_idx<MODE>(x, w)] | ((unsigned)row[border_idx<MODE>(x + 1, w)] << 8) |
-                           ((unsigned)row[border_idx<MODE>(x + 2, w)] << 16) | ((unsigned)row[border_idx<MODE>(x + 3, w)] << 24);
-            }
-            v[k] = val;
-        }
-    }
-    template <int DSTRIDE>
-    __device__ __forceinline__ void park(unsigned* __restrict__ dst, int tid) const
-    {
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int i = tid + k * NT;
-            if (i < ROWS * WORDS) { const int r = i / WORDS, c = i - r * WORDS; dst[r * DSTRIDE + c] = v[k]; }
-        }
-    }
-};
-
 // bytes -1 .. 4 around the dword b (a = previous dword, c = next dword)
 __device__ __forceinline__ void unpack6(unsigned a, unsigned b, unsigned c, int* p /* p[0] = byte -1 ... p[5] = byte 4 */)
 {

@@ -9,7 +9,7 @@ TCC block has 4 counter slots, FETCH_SIZE takes 3, WRITE_SIZE 2) of ONE device p
 Units and corrections as MI355X_MICROARCH.md (HBM section) prescribes: both counters report KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of wide coalesced streaming reads (x2), WRITE_SIZE is taken as is.  The stage's dispatches: k_grey,
 k_blur (or k_median3 + k_gauss357), k_median57, the main-Canny Sobel/NMS dispatch (the smaller of the two
-k_sobel_nms_planes grids, or k_sobel_nms_src) and the hysteresis launches that precede the HoughCircles Sobel/NMS dispatch.
+k_sobel_nms_rows grids, or k_sobel_nms_src) and the hysteresis launches that precede the HoughCircles Sobel/NMS dispatch.
 The output records the hash of the kernel sources (bench.py refuses the figure when the kernels have changed since)."""
 import hashlib
 import json
@@ -51,14 +51,14 @@ def stage_counts(db_path, counter):
         e = disp.setdefault(d, [k, gsz, 0.0])
         e[2] += v
     order = sorted(disp)
-    sobel = [d for d in order if disp[d][0] == "k_sobel_nms_planes"]
+    sobel = [d for d in order if disp[d][0] == "k_sobel_nms_rows"]
     hc_sobel = max(sobel, key=lambda d: disp[d][1]) if len(sobel) > 1 else None       # the 7-plane HoughCircles dispatch
     out = {}
     for d in order:
         k, gsz, v = disp[d]
         if k in STAGE:
             out[k] = out.get(k, 0.0) + v
-        elif k == "k_sobel_nms_src" or (k == "k_sobel_nms_planes" and d != hc_sobel):
+        elif k == "k_sobel_nms_src" or (k == "k_sobel_nms_rows" and d != hc_sobel):
             out["k_sobel_nms(main Canny)"] = out.get("k_sobel_nms(main Canny)", 0.0) + v
         elif k == "k_hysteresis" and (hc_sobel is None or d < hc_sobel):
             out["k_hysteresis(main Canny)"] = out.get("k_hysteresis(main Canny)", 0.0) + v
