@@ -51,11 +51,15 @@ def cpu_baseline(per_worker):
     return json.loads(out.decode().strip().splitlines()[-1])
 
 
+# the sources of the blur+Canny stage's kernels (and what they include)
+STAGE_SOURCES = ("i2s_types.h", "k_canny.h", "k_canny_rows.h", "k_filters.h", "tile_io.h")
+
+
 def kernels_sha():
     """Hash of the kernel sources: PMC traffic figures are only valid for the kernels they were collected on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "img2sgf_amd", "csrc")
-    for f in sorted(os.listdir(d)):
+    for f in STAGE_SOURCES:
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

@@ -9,6 +9,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/i2s.h"
 
 namespace i2s {
@@ -26,14 +28,23 @@ struct RcclApi {
     char err[256] = {0};
 };
 
+static void rccl_open(RcclApi& api);
+
+// the library is opened once per process, whichever thread asks first
 static RcclApi* rccl_api()
 {
     static RcclApi api;
-    if (api.handle) return &api;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_open(api); });
+    return api.handle ? &api : nullptr;
+}
+
+static void rccl_open(RcclApi& api)
+{
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
-    if (!h) { snprintf(api.err, sizeof(api.err), "librccl not found: %s", dlerror()); return nullptr; }
+    if (!h) { snprintf(api.err, sizeof(api.err), "librccl not found: %s", dlerror()); return; }
     api.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (int (*)(rccl_comm_t*, int, RcclId, int))dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
@@ -42,10 +53,9 @@ static RcclApi* rccl_api()
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
         snprintf(api.err, sizeof(api.err), "librccl lacks an ncclGetUniqueId/CommInitRank/CommDestroy/AllGather/GetErrorString symbol");
         dlclose(h);
-        return nullptr;
+        return;
     }
     api.handle = h;
-    return &api;
 }
 
 }  // namespace i2s

@@ -120,7 +120,10 @@ typedef struct i2s_params {
     int32_t grey_shift;                /* 15 (4.x) | 14 (3.x) */
     int32_t gauss_kernel_mode;         /* 0 = error-diffused taps summing to 256 | 1 = plain rounding */
     int32_t houghlines_numangle_mode;  /* 0 = floor+1 with pi-wrap fix (current) | 1 = cvRound (legacy) */
-    int32_t inputs_on_device;          /* 1: img[] are device pointers (no copy); 0: host pointers */
+    int32_t inputs_on_device;          /* 1: img[] are device pointers, read IN PLACE (no copy): a single-channel image with 4-byte
+                                          aligned rows also serves as its own grey plane, so it must stay valid and unchanged until
+                                          the next detect call if i2s_classify_batch / i2s_fetch_plane(GREY) are used on it;
+                                          0: host pointers (staged into the context) */
     /* Pillow pre-processing on the device (img2sgf.py:141-149): contrast / brightness slider values 0..100, the
      * reference's defaults are 70 / 50.  -1 (default) = off: img[] already is `input_image_np` (:150). */
     int32_t contrast, brightness;

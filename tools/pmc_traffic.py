@@ -22,10 +22,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE = ("k_grey", "k_blur", "k_median3", "k_gauss357", "k_median57")
 
 
+# the sources of the blur+Canny stage's kernels (and what they include)
+STAGE_SOURCES = ("i2s_types.h", "k_canny.h", "k_canny_rows.h", "k_filters.h", "tile_io.h")
+
+
 def kernels_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "img2sgf_amd", "csrc")
-    for f in sorted(os.listdir(d)):
+    for f in STAGE_SOURCES:
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
