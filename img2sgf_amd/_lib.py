@@ -38,7 +38,7 @@ class I2sParams(C.Structure):
         ("grey_shift", C.c_int32), ("gauss_kernel_mode", C.c_int32), ("houghlines_numangle_mode", C.c_int32),
         ("inputs_on_device", C.c_int32),
         ("contrast", C.c_int32), ("brightness", C.c_int32),
-        ("schedule", C.c_int32), ("pad_", C.c_int32),
+        ("schedule", C.c_int32), ("jpeg_entropy_device", C.c_int32),
     ]
 
 

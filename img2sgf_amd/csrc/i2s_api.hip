@@ -60,6 +60,9 @@ struct i2s_ctx {
     size_t jpg_bytes = 0;
     JpgDesc* d_jd = nullptr;     // [max_batch]
     JpgDesc* h_jd = nullptr;
+    uint8_t* d_jh = nullptr;     // entropy decoding on the device: file bytes | Huffman tables | scans | images | status (grown on demand)
+    size_t jh_bytes = 0;
+    int* h_jstatus = nullptr;    // [max_batch] pinned
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
     int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
@@ -118,7 +121,7 @@ extern "C" void i2s_default_params(i2s_params* p)
     p->line_threshold = 0; p->black_threshold = 128;
     p->align_x = I2S_ALIGN_LEFT; p->align_y = I2S_ALIGN_TOP;
     p->min_grid_spacing = 10; p->big_space_ratio = 1.6; p->angle_tolerance_deg = 1.0;
-    p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 0; p->inputs_on_device = 0; p->schedule = 0; p->pad_ = 0;
+    p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 0; p->inputs_on_device = 0; p->schedule = 0; p->jpeg_entropy_device = 0;
     p->contrast = -1; p->brightness = -1;
 }
 
@@ -150,9 +153,9 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh};
     for (void* q : dev) if (q) (void)hipFree(q);
-    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd};
+    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus};
     for (void* q : host) if (q) (void)hipHostFree(q);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i <= I2S_NSEG; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
@@ -202,6 +205,7 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipHostMalloc(&ctx->h_xf, nb * sizeof(XfDesc)));
     I2S_HIP(hipMalloc(&ctx->d_jd, nb * sizeof(JpgDesc)));
     I2S_HIP(hipHostMalloc(&ctx->h_jd, nb * sizeof(JpgDesc)));
+    I2S_HIP(hipHostMalloc(&ctx->h_jstatus, nb * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_flags, 2 * HYST_MAX_PASSES * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_flags, 2 * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * g.cent_cap * sizeof(unsigned)));
@@ -738,7 +742,8 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
         // layout first, then the entropy decoding of the pass's images on the host: independent bit streams, one task each,
         // spread over a few threads (Huffman decoding runs at ~130 MB/s of file data per core: alone it would be 80 % of the
         // wall time of a pass of scans)
-        if (coef.size() < ncoef / sizeof(int16_t)) coef.resize(ncoef / sizeof(int16_t));
+        const bool on_device = p->jpeg_entropy_device != 0;      // entropy decoding: one lane per file on the device, or host threads
+        if (!on_device && coef.size() < ncoef / sizeof(int16_t)) coef.resize(ncoef / sizeof(int16_t));
         size_t co = 0, po = ncoef, ro = ncoef + nplane;
         int wmax = 0, hmax = 0, max_blocks = 0;
         std::vector<int16_t*> cps((size_t)nb * 3, nullptr);
@@ -753,7 +758,7 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
             }
             for (int c = 0; c < f.ncomp; c++) {
                 const size_t nblk = (size_t)f.c[c].bw * f.c[c].bh;
-                cps[(size_t)i * 3 + c] = coef.data() + co / sizeof(int16_t);
+                cps[(size_t)i * 3 + c] = on_device ? nullptr : coef.data() + co / sizeof(int16_t);
                 cbytes[(size_t)i * 3 + c] = nblk * 64 * sizeof(int16_t);
                 J.coef[c] = reinterpret_cast<const int16_t*>(ctx->d_jpg + co);
                 J.plane[c] = ctx->d_jpg + po;
@@ -772,7 +777,68 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
             wmax = f.X > wmax ? f.X : wmax; hmax = f.Y > hmax ? f.Y : hmax;
             max_blocks = blocks > max_blocks ? blocks : max_blocks;
         }
-        {
+        if (on_device) {
+            // entropy decoding on the device: upload the file bytes (not the 15 x larger coefficient arrays), the distinct
+            // Huffman tables of the pass and one record per scan and image; one lane per file decodes (k_jpeg_huffman)
+            std::vector<JpegHuff> tabs;
+            std::vector<JpgHuffScan> hscans;
+            std::vector<JpgHuffImg> himgs(nb);
+            auto tab_index = [&](const JpegHuff& h) -> int {
+                if (!h.present) return -1;
+                for (size_t t = tabs.size(); t-- > 0;)                  // newest first: consecutive scans mostly share tables
+                    if (memcmp(&tabs[t], &h, sizeof(JpegHuff)) == 0) return (int)t;
+                tabs.push_back(h);
+                return (int)tabs.size() - 1;
+            };
+            size_t blob = 0;
+            for (int i = 0; i < nb; i++) blob += align256(len[order[first + i]]);
+            std::vector<uint8_t> bytes(blob);
+            size_t bo = 0;
+            for (int i = 0; i < nb; i++) {
+                const int k = order[first + i];
+                const JpegFile& f = files[i];
+                memcpy(bytes.data() + bo, jpeg[k], len[k]);
+                JpgHuffImg& hi = himgs[i];
+                hi.f = jpg_frame_view(f);
+                hi.scan0 = (int)hscans.size(); hi.nscans = (int)f.scans.size();
+                for (int c = 0; c < 3; c++) hi.coef[c] = const_cast<int16_t*>(ctx->h_jd[i].coef[c]);
+                for (const JpegScan& sc : f.scans) {
+                    JpgHuffScan hs;
+                    hs.ns = sc.ns; hs.ss = sc.ss; hs.se = sc.se; hs.ah = sc.ah; hs.al = sc.al; hs.dri = sc.dri;
+                    for (int q = 0; q < 3; q++) { hs.ci[q] = sc.ci[q]; hs.td[q] = sc.td[q]; hs.ta[q] = sc.ta[q]; }
+                    for (int t = 0; t < 4; t++) { hs.tab_dc[t] = tab_index(sc.dc[t]); hs.tab_ac[t] = tab_index(sc.ac[t]); }
+                    hs.off = (unsigned)(bo + (size_t)(sc.data - jpeg[k])); hs.len = (unsigned)sc.len;
+                    hscans.push_back(hs);
+                }
+                bo += align256(len[k]);
+            }
+            if (tabs.empty()) tabs.resize(1);
+            const size_t o_tab = align256(blob), o_scan = o_tab + align256(tabs.size() * sizeof(JpegHuff));
+            const size_t o_img = o_scan + align256(hscans.size() * sizeof(JpgHuffScan)), o_st = o_img + align256(nb * sizeof(JpgHuffImg));
+            const size_t need_h = o_st + align256(nb * sizeof(int));
+            if (need_h > ctx->jh_bytes) {
+                I2S_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->d_jh) I2S_HIP(hipFree(ctx->d_jh));
+                ctx->d_jh = nullptr; ctx->jh_bytes = 0;
+                I2S_HIP(hipMalloc(&ctx->d_jh, need_h));
+                ctx->jh_bytes = need_h;
+            }
+            I2S_HIP(hipMemsetAsync(ctx->d_jpg, 0, ncoef, ctx->stream));              // coefficients start at zero
+            I2S_HIP(hipMemcpyAsync(ctx->d_jh, bytes.data(), blob, hipMemcpyHostToDevice, ctx->stream));
+            I2S_HIP(hipMemcpyAsync(ctx->d_jh + o_tab, tabs.data(), tabs.size() * sizeof(JpegHuff), hipMemcpyHostToDevice, ctx->stream));
+            I2S_HIP(hipMemcpyAsync(ctx->d_jh + o_scan, hscans.data(), hscans.size() * sizeof(JpgHuffScan), hipMemcpyHostToDevice, ctx->stream));
+            I2S_HIP(hipMemcpyAsync(ctx->d_jh + o_img, himgs.data(), nb * sizeof(JpgHuffImg), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_jpeg_huffman, dim3(cdiv(nb, 64)), dim3(64), 0, ctx->stream, reinterpret_cast<const JpgHuffImg*>(ctx->d_jh + o_img),
+                               reinterpret_cast<const JpgHuffScan*>(ctx->d_jh + o_scan), reinterpret_cast<const JpegHuff*>(ctx->d_jh + o_tab),
+                               ctx->d_jh, nb, reinterpret_cast<int*>(ctx->d_jh + o_st));
+            I2S_HIP(hipMemcpyAsync(ctx->h_jstatus, ctx->d_jh + o_st, nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            I2S_HIP(hipStreamSynchronize(ctx->stream));       // the host vectors above go out of scope; a corrupt file is reported before anything else runs
+            for (int i = 0; i < nb; i++)
+                if (ctx->h_jstatus[i] != JPG_OK) {
+                    snprintf(ctx->err, sizeof(ctx->err), "JPEG %d: corrupt or truncated entropy-coded data", order[first + i]);
+                    return I2S_E_INVALID;
+                }
+        } else {
             std::atomic<int> next(0), bad(-1);
             auto work = [&]() {
                 for (int i = next.fetch_add(1); i < nb; i = next.fetch_add(1)) {
@@ -794,8 +860,8 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
                 snprintf(ctx->err, sizeof(ctx->err), "JPEG %d: corrupt or truncated entropy-coded data", bad.load());
                 return I2S_E_INVALID;
             }
+            I2S_HIP(hipMemcpyAsync(ctx->d_jpg, coef.data(), ncoef, hipMemcpyHostToDevice, ctx->stream));
         }
-        I2S_HIP(hipMemcpyAsync(ctx->d_jpg, coef.data(), ncoef, hipMemcpyHostToDevice, ctx->stream));
         I2S_HIP(hipMemcpyAsync(ctx->d_jd, ctx->h_jd, nb * sizeof(JpgDesc), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_jpeg_idct, dim3(cdiv(max_blocks, 64), nb), dim3(64), 0, ctx->stream, ctx->d_jd);
         hipLaunchKernelGGL(k_jpeg_rgb, dim3(cdiv(wmax, 64), cdiv(hmax, 4), nb), dim3(64, 4), 0, ctx->stream, ctx->d_jd);

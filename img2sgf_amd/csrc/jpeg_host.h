@@ -16,6 +16,15 @@
 
 #include <vector>
 
+// The entropy decoder below (bit reader, Huffman symbols, sequential and progressive block decoding) is written once and
+// compiled twice: for the host (round 1's path: one file per host thread) and for the device (k_jpeg_huffman, k_jpeg.h: one
+// file per lane).  The marker parser stays host-only.
+#if defined(__HIPCC__) || defined(HIPEMU)
+#define I2S_HD __host__ __device__
+#else
+#define I2S_HD
+#endif
+
 namespace i2s {
 
 struct JpegComp {
@@ -56,6 +65,15 @@ enum { JPG_OK = 0, JPG_BAD = 1, JPG_UNSUPPORTED = 2 };
 static const uint8_t JPG_ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ const uint8_t JPG_ZZ_DEV[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                                        41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                                        30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+#define JPG_ZZ_AT(k) JPG_ZZ_DEV[k]
+#else
+#define JPG_ZZ_AT(k) JPG_ZZ[k]
+#endif
 
 static int jpg_build_huff(const uint8_t* counts, const uint8_t* syms, int nsyms, JpegHuff* h)
 {
@@ -230,8 +248,8 @@ struct JpegBits {
     uint64_t acc = 0; int cnt = 0;
     bool hit_marker = false;
     long long real_bits = 0, used_bits = 0;      // bits delivered from the file / consumed since the last restart
-    JpegBits(const uint8_t* d_, size_t n_) : d(d_), n(n_) {}
-    inline void fill()
+    I2S_HD JpegBits(const uint8_t* d_, size_t n_) : d(d_), n(n_) {}
+    I2S_HD inline void fill()
     {
         // fast path: four data bytes without 0xFF (no stuffing, no marker) enter the accumulator at once
         while (cnt <= 32 && !hit_marker && p + 4 <= n) {
@@ -255,12 +273,12 @@ struct JpegBits {
             cnt += 8;
         }
     }
-    inline unsigned peek(int k) { if (cnt < k) fill(); return (unsigned)(acc >> (cnt - k)) & ((1u << k) - 1u); }
-    inline void skip(int k) { cnt -= k; used_bits += k; }
-    inline bool overrun() const { return used_bits > real_bits; }     // consumed padding zeros: the segment ended early
-    inline unsigned get(int k) { if (k == 0) return 0; const unsigned v = peek(k); skip(k); return v; }
+    I2S_HD inline unsigned peek(int k) { if (cnt < k) fill(); return (unsigned)(acc >> (cnt - k)) & ((1u << k) - 1u); }
+    I2S_HD inline void skip(int k) { cnt -= k; used_bits += k; }
+    I2S_HD inline bool overrun() const { return used_bits > real_bits; }     // consumed padding zeros: the segment ended early
+    I2S_HD inline unsigned get(int k) { if (k == 0) return 0; const unsigned v = peek(k); skip(k); return v; }
     // byte-align and step over the RSTn marker
-    inline bool restart()
+    I2S_HD inline bool restart()
     {
         if (overrun()) return false;
         acc = 0; cnt = 0; real_bits = 0; used_bits = 0;
@@ -274,7 +292,7 @@ struct JpegBits {
     }
 };
 
-static inline int jpg_decode_sym(JpegBits& b, const JpegHuff& h)
+I2S_HD static inline int jpg_decode_sym(JpegBits& b, const JpegHuff& h)
 {
     const unsigned look = b.peek(9);
     const int l = h.look_len[look];
@@ -285,10 +303,10 @@ static inline int jpg_decode_sym(JpegBits& b, const JpegHuff& h)
     return h.syms[(code + h.valoff[len]) & 255];
 }
 
-static inline int jpg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+I2S_HD static inline int jpg_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
 // One block of a sequential scan.
-static inline int jpg_block_sequential(JpegBits& b, const JpegHuff& hd, const JpegHuff& ha, int& pred, int16_t* blk)
+I2S_HD static inline int jpg_block_sequential(JpegBits& b, const JpegHuff& hd, const JpegHuff& ha, int& pred, int16_t* blk)
 {
     int s = jpg_decode_sym(b, hd);
     if (s < 0 || s > 11) return JPG_BAD;
@@ -302,7 +320,7 @@ static inline int jpg_block_sequential(JpegBits& b, const JpegHuff& hd, const Jp
         if (s) {
             k += r;
             if (k > 63) return JPG_BAD;
-            blk[JPG_ZZ[k]] = (int16_t)jpg_extend((int)b.get(s), s);
+            blk[JPG_ZZ_AT(k)] = (int16_t)jpg_extend((int)b.get(s), s);
             k++;
         } else if (r == 15) k += 16;
         else break;
@@ -311,7 +329,7 @@ static inline int jpg_block_sequential(JpegBits& b, const JpegHuff& hd, const Jp
 }
 
 // Progressive AC, first pass of a band (jdphuff.c decode_mcu_AC_first).
-static inline int jpg_block_ac_first(JpegBits& b, const JpegHuff& ha, int ss, int se, int al, unsigned& eobrun, int16_t* blk)
+I2S_HD static inline int jpg_block_ac_first(JpegBits& b, const JpegHuff& ha, int ss, int se, int al, unsigned& eobrun, int16_t* blk)
 {
     if (eobrun > 0) { eobrun--; return JPG_OK; }
     for (int k = ss; k <= se; k++) {
@@ -321,7 +339,7 @@ static inline int jpg_block_ac_first(JpegBits& b, const JpegHuff& ha, int ss, in
         if (s) {
             k += r;
             if (k > 63) return JPG_BAD;
-            blk[JPG_ZZ[k]] = (int16_t)(jpg_extend((int)b.get(s), s) * (1 << al));
+            blk[JPG_ZZ_AT(k)] = (int16_t)(jpg_extend((int)b.get(s), s) * (1 << al));
         } else if (r == 15) k += 15;
         else {
             eobrun = 1u << r;
@@ -335,7 +353,7 @@ static inline int jpg_block_ac_first(JpegBits& b, const JpegHuff& ha, int ss, in
 
 // Progressive AC, refinement pass (jdphuff.c decode_mcu_AC_refine): one more bit for the coefficients that are already
 // non-zero, and newly non-zero coefficients (+-1 << al) placed after skipping r zero-valued positions.
-static inline int jpg_block_ac_refine(JpegBits& b, const JpegHuff& ha, int ss, int se, int al, unsigned& eobrun, int16_t* blk)
+I2S_HD static inline int jpg_block_ac_refine(JpegBits& b, const JpegHuff& ha, int ss, int se, int al, unsigned& eobrun, int16_t* blk)
 {
     const int p1 = 1 << al, m1 = -(1 << al);
     int k = ss;
@@ -354,7 +372,7 @@ static inline int jpg_block_ac_refine(JpegBits& b, const JpegHuff& ha, int ss, i
             }
             // advance over already-non-zero coefficients (each takes a correction bit) and r zero ones
             do {
-                int16_t* c = blk + JPG_ZZ[k];
+                int16_t* c = blk + JPG_ZZ_AT(k);
                 if (*c != 0) {
                     if (b.get(1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
                 } else if (--r < 0) break;
@@ -362,13 +380,13 @@ static inline int jpg_block_ac_refine(JpegBits& b, const JpegHuff& ha, int ss, i
             } while (k <= se);
             if (s) {
                 if (k > 63) return JPG_BAD;
-                blk[JPG_ZZ[k]] = (int16_t)s;
+                blk[JPG_ZZ_AT(k)] = (int16_t)s;
             }
         }
     }
     if (eobrun > 0) {
         for (; k <= se; k++) {
-            int16_t* c = blk + JPG_ZZ[k];
+            int16_t* c = blk + JPG_ZZ_AT(k);
             if (*c != 0 && b.get(1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
         }
         eobrun--;
@@ -376,49 +394,83 @@ static inline int jpg_block_ac_refine(JpegBits& b, const JpegHuff& ha, int ss, i
     return JPG_OK;
 }
 
-// coef[c]: bh * bw blocks of 64 int16 in natural order, zero-initialised by the caller; all scans are applied in file order.
+// What the entropy decoder needs to know about a frame and about one scan (plain data: the device gets it in this form).
+struct JpegFrameView {
+    int progressive, ncomp, mcux, mcuy;
+    JpegComp c[3];
+};
+struct JpegScanView {
+    int ns, ci[3], td[3], ta[3], ss, se, ah, al, dri;
+    const JpegHuff* dc[4];
+    const JpegHuff* ac[4];
+    const uint8_t* data;
+    size_t len;
+};
+
+// One scan.  coef[c]: bh * bw blocks of 64 int16 in natural order, zero-initialised before the first scan.
+I2S_HD static inline int jpg_decode_scan_view(const JpegFrameView& f, const JpegScanView& sc, int16_t* const coef[3])
+{
+    JpegBits b(sc.data, sc.len);
+    int pred[3] = {0, 0, 0};
+    unsigned eobrun = 0;
+    long long cnt = 0;
+    // a scan of one component is not interleaved: its MCU is one block and it covers only the blocks that hold image samples
+    const bool single = sc.ns == 1;
+    const JpegComp& c0 = f.c[sc.ci[0]];
+    const int nx = single ? (c0.dw + 7) / 8 : f.mcux, ny = single ? (c0.dh + 7) / 8 : f.mcuy;
+    for (int my = 0; my < ny; my++)
+        for (int mx = 0; mx < nx; mx++) {
+            if (sc.dri && cnt && cnt % sc.dri == 0) {
+                if (!b.restart()) return JPG_BAD;
+                pred[0] = pred[1] = pred[2] = 0;
+                eobrun = 0;
+            }
+            cnt++;
+            for (int k = 0; k < sc.ns; k++) {
+                const JpegComp& jc = f.c[sc.ci[k]];
+                const int nbx = single ? 1 : jc.h, nby = single ? 1 : jc.v;
+                for (int by = 0; by < nby; by++)
+                    for (int bx = 0; bx < nbx; bx++) {
+                        const int row = single ? my : my * jc.v + by, col = single ? mx : mx * jc.h + bx;
+                        int16_t* blk = coef[sc.ci[k]] + ((size_t)row * jc.bw + (size_t)col) * 64;
+                        int rc = JPG_OK;
+                        if (!f.progressive) rc = jpg_block_sequential(b, *sc.dc[sc.td[k]], *sc.ac[sc.ta[k]], pred[k], blk);
+                        else if (sc.ss == 0) {
+                            if (sc.ah == 0) {                    // DC first pass: the difference, scaled
+                                const int s = jpg_decode_sym(b, *sc.dc[sc.td[k]]);
+                                if (s < 0 || s > 11) return JPG_BAD;
+                                pred[k] += s ? jpg_extend((int)b.get(s), s) : 0;
+                                blk[0] = (int16_t)(pred[k] * (1 << sc.al));
+                            } else if (b.get(1)) blk[0] = (int16_t)(blk[0] | (1 << sc.al));      // DC refinement: one bit
+                        } else if (sc.ah == 0) rc = jpg_block_ac_first(b, *sc.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
+                        else rc = jpg_block_ac_refine(b, *sc.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
+                        if (rc) return rc;
+                    }
+            }
+        }
+    return b.overrun() ? JPG_BAD : JPG_OK;
+}
+
+static inline JpegFrameView jpg_frame_view(const JpegFile& f)
+{
+    JpegFrameView v;
+    v.progressive = f.progressive ? 1 : 0; v.ncomp = f.ncomp; v.mcux = f.mcux; v.mcuy = f.mcuy;
+    for (int c = 0; c < 3; c++) v.c[c] = f.c[c];
+    return v;
+}
+
+// Host path: all scans of a parsed file, in file order.
 static int jpg_decode_scan(const JpegFile& f, int16_t* const coef[3])
 {
+    const JpegFrameView fv = jpg_frame_view(f);
     for (const JpegScan& sc : f.scans) {
-        JpegBits b(sc.data, sc.len);
-        int pred[3] = {0, 0, 0};
-        unsigned eobrun = 0;
-        long long cnt = 0;
-        // a scan of one component is not interleaved: its MCU is one block and it covers only the blocks that hold image samples
-        const bool single = sc.ns == 1;
-        const JpegComp& c0 = f.c[sc.ci[0]];
-        const int nx = single ? (c0.dw + 7) / 8 : f.mcux, ny = single ? (c0.dh + 7) / 8 : f.mcuy;
-        for (int my = 0; my < ny; my++)
-            for (int mx = 0; mx < nx; mx++) {
-                if (sc.dri && cnt && cnt % sc.dri == 0) {
-                    if (!b.restart()) return JPG_BAD;
-                    pred[0] = pred[1] = pred[2] = 0;
-                    eobrun = 0;
-                }
-                cnt++;
-                for (int k = 0; k < sc.ns; k++) {
-                    const JpegComp& jc = f.c[sc.ci[k]];
-                    const int nbx = single ? 1 : jc.h, nby = single ? 1 : jc.v;
-                    for (int by = 0; by < nby; by++)
-                        for (int bx = 0; bx < nbx; bx++) {
-                            const int row = single ? my : my * jc.v + by, col = single ? mx : mx * jc.h + bx;
-                            int16_t* blk = coef[sc.ci[k]] + ((size_t)row * jc.bw + (size_t)col) * 64;
-                            int rc = JPG_OK;
-                            if (!f.progressive) rc = jpg_block_sequential(b, sc.dc[sc.td[k]], sc.ac[sc.ta[k]], pred[k], blk);
-                            else if (sc.ss == 0) {
-                                if (sc.ah == 0) {                    // DC first pass: the difference, scaled
-                                    const int s = jpg_decode_sym(b, sc.dc[sc.td[k]]);
-                                    if (s < 0 || s > 11) return JPG_BAD;
-                                    pred[k] += s ? jpg_extend((int)b.get(s), s) : 0;
-                                    blk[0] = (int16_t)(pred[k] * (1 << sc.al));
-                                } else if (b.get(1)) blk[0] = (int16_t)(blk[0] | (1 << sc.al));      // DC refinement: one bit
-                            } else if (sc.ah == 0) rc = jpg_block_ac_first(b, sc.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
-                            else rc = jpg_block_ac_refine(b, sc.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
-                            if (rc) return rc;
-                        }
-                }
-            }
-        if (b.overrun()) return JPG_BAD;
+        JpegScanView v;
+        v.ns = sc.ns; v.ss = sc.ss; v.se = sc.se; v.ah = sc.ah; v.al = sc.al; v.dri = sc.dri;
+        for (int k = 0; k < 3; k++) { v.ci[k] = sc.ci[k]; v.td[k] = sc.td[k]; v.ta[k] = sc.ta[k]; }
+        for (int t = 0; t < 4; t++) { v.dc[t] = &sc.dc[t]; v.ac[t] = &sc.ac[t]; }
+        v.data = sc.data; v.len = sc.len;
+        const int rc = jpg_decode_scan_view(fv, v, coef);
+        if (rc) return rc;
     }
     return JPG_OK;
 }

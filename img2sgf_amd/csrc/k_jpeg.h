@@ -8,6 +8,7 @@
 // Pinned against Pillow itself (tests/test_gpu_jpeg.py, tests/test_emu_pipeline.py).
 #pragma once
 #include "i2s_types.h"
+#include "jpeg_host.h"
 
 namespace i2s {
 
@@ -21,6 +22,48 @@ struct JpgDesc {
     int nblocks[3];             // bw * bh
     unsigned short q[3][64];    // quantisation tables of the components, natural order
 };
+
+// ---- entropy decoding on the device: one lane per file runs the decoder of jpeg_host.h (the same source, compiled
+// for the device) over the file's scans in order.  A Huffman stream is serial -- every symbol's position depends on the one
+// before -- and a lane needs a few hundred cycles per symbol (table lookups are dependent loads), so ONE file takes tens of
+// milliseconds; the device wins on batches: a pass of 256 files keeps 256 lanes busy for the time the slowest file takes,
+// where the host path spreads the files over at most 16 threads.  Restart intervals and the independent scans of a
+// progressive file would add lanes per file; not used yet.
+struct JpgHuffScan {
+    int ns, ci[3], td[3], ta[3], ss, se, ah, al, dri;
+    int tab_dc[4], tab_ac[4];     // indices into the pass's table pool (-1: not defined at this scan)
+    unsigned off, len;            // entropy-coded segment inside the pass's byte blob
+};
+struct JpgHuffImg {
+    JpegFrameView f;
+    int scan0, nscans;
+    int16_t* coef[3];
+};
+
+// grid (ceil(nb / 64)), block 64.  status[i] = JPG_OK / JPG_BAD.
+__global__ __launch_bounds__(64) void k_jpeg_huffman(const JpgHuffImg* __restrict__ imgs, const JpgHuffScan* __restrict__ scans,
+                                                     const JpegHuff* __restrict__ tabs, const uint8_t* __restrict__ bytes, int nb,
+                                                     int* __restrict__ status)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nb) return;
+    const JpgHuffImg& im = imgs[i];
+    int16_t* coef[3] = {im.coef[0], im.coef[1], im.coef[2]};
+    int rc = JPG_OK;
+    for (int s = 0; s < im.nscans && rc == JPG_OK; s++) {
+        const JpgHuffScan& hs = scans[im.scan0 + s];
+        JpegScanView v;
+        v.ns = hs.ns; v.ss = hs.ss; v.se = hs.se; v.ah = hs.ah; v.al = hs.al; v.dri = hs.dri;
+        for (int k = 0; k < 3; k++) { v.ci[k] = hs.ci[k]; v.td[k] = hs.td[k]; v.ta[k] = hs.ta[k]; }
+        for (int t = 0; t < 4; t++) {
+            v.dc[t] = tabs + (hs.tab_dc[t] < 0 ? 0 : hs.tab_dc[t]);
+            v.ac[t] = tabs + (hs.tab_ac[t] < 0 ? 0 : hs.tab_ac[t]);
+        }
+        v.data = bytes + hs.off; v.len = hs.len;
+        rc = jpg_decode_scan_view(im.f, v, coef);
+    }
+    status[i] = rc;
+}
 
 // One pass of the LL&M inverse DCT over 8 values; SHIFT = 11 (columns) or 18 (rows).
 template <int SHIFT>

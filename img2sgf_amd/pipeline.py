@@ -43,6 +43,7 @@ class Params:
     contrast: Optional[int] = None     # 0..100: ImageEnhance.Contrast on the device (img2sgf.py:141-144); None = input is already enhanced
     brightness: Optional[int] = None   # 0..100: ImageEnhance.Brightness on the device (:146-149)
     schedule: bool = False             # ragged batches larger than one device pass: form the passes over images sorted by area
+    jpeg_entropy_device: bool = False  # detect_jpeg: Huffman decoding on the device (one lane per file) instead of host threads
 
     def to_c(self, inputs_on_device=False):
         p = I2sParams()
@@ -60,6 +61,7 @@ class Params:
         p.contrast = -1 if self.contrast is None else int(self.contrast)
         p.brightness = -1 if self.brightness is None else int(self.brightness)
         p.schedule = 1 if self.schedule else 0
+        p.jpeg_entropy_device = 1 if self.jpeg_entropy_device else 0
         return p
 
 

@@ -20,7 +20,7 @@
  *   i2s_detect_batch_xf   the same, preceded on the device by crop_and_rotate_image() 110-114
  *                         (PIL Image.rotate(NEAREST, fillcolor white, center) + Image.crop).
  *   i2s_detect_jpeg_batch the same from JPEG bytes: Image.open(...).convert("RGB") 651 for Huffman JPEGs, decoded on
- *                         the device (Huffman stage on the host).
+ *                         the device (marker parsing on the host; entropy decoding, IDCT, upsampling, colour on the device).
  *   i2s_fetch_source      input_image_np 150 after the on-device rotate / crop (110-114) and contrast / brightness
  *                         (141-149) steps, if enabled.
  *   i2s_comm_* / i2s_allgather_boards / i2s_set_board_sink
@@ -130,7 +130,11 @@ typedef struct i2s_params {
     /* Ragged batches: != 0 lets a call with more images than one device pass holds form its passes over the
      * images sorted by area, so that a pass's tile grids (sized for its largest image) are not mostly empty; results are
      * returned in input order.  The "last pass" the fetch / classify calls refer to is then the pass of the largest images. */
-    int32_t schedule, pad_;
+    int32_t schedule;
+    /* i2s_detect_jpeg_batch: 0 (default) = Huffman decoding on host threads; 1 = on the device, one lane per file (the same
+     * decoder source, bit-exact; a lane decodes far slower than a core, so it only pays for passes of thousands of files:
+     * DESIGN.md 6c holds the measured rates) */
+    int32_t jpeg_entropy_device;
 } i2s_params;
 
 /* Compact per-image record: what the SGF writer needs (to_SGF 781-810) and what ranks
@@ -210,8 +214,9 @@ int  i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* img,
                          const i2s_xform* xf, const i2s_params* p, i2s_board* boards, i2s_result* full);
 
 /* JPEG input: Image.open(path).convert("RGB") (img2sgf.py:651) for 8-bit Huffman JPEGs, sequential or
- * progressive (grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, any scan script), bit-exact with Pillow / libjpeg-turbo: entropy decoding
- * on the host, dequantisation + inverse DCT + chroma upsampling + colour conversion on the device, then the ordinary path (xf
+ * progressive (grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, any scan script), bit-exact with Pillow / libjpeg-turbo: marker parsing
+ * on the host, entropy decoding on host threads (i2s_params.jpeg_entropy_device = 1: on the device, one lane per file), dequantisation +
+ * inverse DCT + chroma upsampling + colour conversion on the device, then the ordinary path (xf
  * and the contrast / brightness step of p apply to the decoded image).  I2S_E_UNSUPPORTED for any other flavour (arithmetic
  * coding, CMYK, RGB-coded, 12-bit, lossless): nothing is approximated, decode those elsewhere and use i2s_detect_batch(_xf).
  * i2s_jpeg_info reports the frame size (and 1 or 3 components) or the same error codes without decoding. */

@@ -220,10 +220,16 @@ def test_jpeg_decode_matches_pillow(lib):
     blobs.append(buf.getvalue())
     refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
     det = Detector(0, len(blobs), 300, 260, lib=lib)
-    dets = det.detect_jpeg(blobs, Params(), full=True)
+    dets = det.detect_jpeg(blobs, Params(jpeg_entropy_device=True), full=True)
     for k, (d, r) in enumerate(zip(dets, refs)):
         np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d" % k)
         parity.compare_detection(d, opipe.process_image(r))
+    # the same decoder source on host threads (the default) instead of one lane per file
+    det.detect_jpeg(blobs, Params(), full=False)
+    for k, r in enumerate(refs):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d, host entropy" % k)
+    with pytest.raises(I2sError):
+        det.detect_jpeg([blobs[0][:len(blobs[0]) // 2] + b"\xff\xd9"], Params(jpeg_entropy_device=True), full=False)      # truncated entropy data, device path
     buf = io.BytesIO()
     Image.fromarray(np.zeros((24, 24, 4), np.uint8), "CMYK").save(buf, "JPEG")
     with pytest.raises(I2sError):

@@ -26,16 +26,22 @@ def _blob(name):
         return f.read()
 
 
-def test_all_fixtures_from_file_bytes():
+@pytest.fixture(params=[False, True], ids=["entropy-host", "entropy-device"])
+def on_device(request):
+    """i2s_params.jpeg_entropy_device: Huffman decoding on host threads (default) or one lane per file on the device."""
+    return request.param
+
+
+def test_all_fixtures_from_file_bytes(on_device):
     """File bytes in, the whole reference flow on the device: decode, contrast 70 / brightness 50, detection."""
     names = list(IMAGES)
     blobs = [_blob(n) for n in names]
     refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
     det = Detector(0, len(names), max(r.shape[1] for r in refs), max(r.shape[0] for r in refs))
-    det.detect_jpeg(blobs, Params(), full=False)
+    det.detect_jpeg(blobs, Params(jpeg_entropy_device=on_device), full=False)
     for k, n in enumerate(names):
         np.testing.assert_array_equal(det.fetch_source(k, 3), refs[k], err_msg=n)
-    boards = det.detect_jpeg(blobs, Params(contrast=70, brightness=50), full=False)
+    boards = det.detect_jpeg(blobs, Params(contrast=70, brightness=50, jpeg_entropy_device=on_device), full=False)
     for k, n in enumerate(names):
         want = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n))
         np.testing.assert_array_equal(det.fetch_source(k, 3), want, err_msg=n)
@@ -46,13 +52,13 @@ def test_all_fixtures_from_file_bytes():
     det.close()
 
 
-def test_unsupported_or_broken_files_are_refused():
+def test_unsupported_or_broken_files_are_refused(on_device):
     det = Detector(0, 1, 800, 800)
     buf = io.BytesIO()
     Image.fromarray(np.zeros((40, 40, 4), np.uint8), "CMYK").save(buf, "JPEG")
     for blob in (buf.getvalue(), b"\xff\xd8 not a jpeg", _blob("ex9.jpg")[:4000], _blob("ex3.jpg")[:30000]):
         with pytest.raises(I2sError):
-            det.detect_jpeg([blob], Params(), full=False)
+            det.detect_jpeg([blob], Params(jpeg_entropy_device=on_device), full=False)
     with pytest.raises(I2sError):
         det.jpeg_info(buf.getvalue())
     assert det.jpeg_info(_blob("ex1.jpg")) == (750, 747, 1)          # progressive, greyscale
@@ -92,7 +98,7 @@ def _encode_random(rng):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("I2S_JPEG_SEEDS", 24))))
-def test_pillow_encoded_images(seed):
+def test_pillow_encoded_images(seed, on_device):
     """Random content and sizes from 1x1, every encoder setting Pillow offers (subsampling, quality, optimised Huffman tables,
     restart intervals, progressive scan scripts); every third seed adds the device rotate / crop on top."""
     rng = np.random.default_rng(7000 + seed)
@@ -109,7 +115,7 @@ def test_pillow_encoded_images(seed):
             xfs.append(preprocess.xform((w, h), ang, sel))
             wants.append(np.array(Image.fromarray(r).rotate(angle=-ang, fillcolor="white", center=preprocess.rectangle_centre(sel)).crop(sel)))
     det = Detector(0, 5, 310, 310)
-    dets = det.detect_jpeg(blobs, Params(), full=True, xforms=xfs)
+    dets = det.detect_jpeg(blobs, Params(jpeg_entropy_device=on_device), full=True, xforms=xfs)
     for k, (d, want) in enumerate(zip(dets, wants)):
         np.testing.assert_array_equal(det.fetch_source(k, 3), want, err_msg="image %d" % k)
         if d.status != 100:
@@ -124,8 +130,8 @@ def test_multi_pass_scheduled_jpeg_batch():
     want = [bytes(b) for b in det.detect_jpeg(blobs, Params(), full=False)]
     det.close()
     det = Detector(0, 4, 310, 310)
-    for sched in (False, True):
-        got = det.detect_jpeg(blobs, Params(schedule=sched), full=False)
+    for sched, dev in ((False, False), (True, False), (False, True), (True, True)):
+        got = det.detect_jpeg(blobs, Params(schedule=sched, jpeg_entropy_device=dev), full=False)
         assert [bytes(b) for b in got] == want
     det.close()
 
