@@ -42,12 +42,17 @@ struct JpegHuff {
     uint8_t syms[256];
 };
 
+struct JpegRst { size_t pos, nstuff; };      // an RSTn marker: offset of its FF inside the scan's data, stuffed FF00 pairs before it
 struct JpegScan {
     int ns = 0, ci[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
     int ss = 0, se = 63, ah = 0, al = 0, dri = 0;
     JpegHuff dc[4], ac[4];     // the tables in force at this SOS (they may be redefined between scans)
     const uint8_t* data = nullptr;
     size_t len = 0;
+    // what the walk over the entropy-coded data met (the parallel decoder lays its segments out from this)
+    size_t nstuff = 0;         // stuffed FF00 pairs
+    bool clean = true;         // nothing but stuffed bytes and RSTn markers after an FF (no fill bytes, no FF as the last byte)
+    std::vector<JpegRst> rst;
 };
 
 struct JpegFile {
@@ -222,11 +227,15 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
             // the entropy-coded segment runs up to the next marker that is neither a stuffed FF00 nor RSTn
             size_t q0 = p + L, q = q0;
             while (q < n) {
-                if (d[q] == 0xFF && q + 1 < n && d[q + 1] != 0 && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7)) {
-                    if (d[q + 1] == 0xFF) { q++; continue; }         // fill byte
-                    break;
-                }
-                q++;
+                const uint8_t* ff = static_cast<const uint8_t*>(memchr(d + q, 0xFF, n - q));
+                if (!ff) { q = n; break; }
+                q = (size_t)(ff - d);
+                if (q + 1 >= n) { sc.clean = false; q = n; break; }
+                const int nx = d[q + 1];
+                if (nx == 0) { sc.nstuff++; q += 2; }
+                else if (nx >= 0xD0 && nx <= 0xD7) { sc.rst.push_back(JpegRst{q - q0, sc.nstuff}); q += 2; }
+                else if (nx == 0xFF) { sc.clean = false; q++; }      // fill byte
+                else break;
             }
             sc.data = d + q0; sc.len = q - q0;
             f->scans.push_back(sc);
@@ -457,6 +466,28 @@ static inline JpegFrameView jpg_frame_view(const JpegFile& f)
     v.progressive = f.progressive ? 1 : 0; v.ncomp = f.ncomp; v.mcux = f.mcux; v.mcuy = f.mcuy;
     for (int c = 0; c < 3; c++) v.c[c] = f.c[c];
     return v;
+}
+
+// Host half of the parallel entropy decoder (k_jpeg_entropy.h).  A `clean` scan is cut at its RSTn markers into restart
+// intervals; jpg_interval gives interval i's raw bytes and its size once the stuffing is removed, jpg_destuff removes it
+// (FF00 -> FF; one memchr per 0xFF byte, a few GB/s).
+static inline void jpg_interval(const JpegScan& sc, size_t i, size_t* raw0, size_t* raw_len, size_t* nbytes)
+{
+    const size_t a = i == 0 ? 0 : sc.rst[i - 1].pos + 2, b = i < sc.rst.size() ? sc.rst[i].pos : sc.len;
+    const size_t st = (i < sc.rst.size() ? sc.rst[i].nstuff : sc.nstuff) - (i == 0 ? 0 : sc.rst[i - 1].nstuff);
+    *raw0 = a; *raw_len = b - a; *nbytes = b - a - st;
+}
+static inline size_t jpg_destuff(const uint8_t* d, size_t n, uint8_t* out)
+{
+    size_t p = 0, o = 0;
+    while (p < n) {
+        const uint8_t* ff = static_cast<const uint8_t*>(memchr(d + p, 0xFF, n - p));
+        const size_t q = ff ? (size_t)(ff - d) + 1 : n;           // the FF itself is data
+        memcpy(out + o, d + p, q - p);
+        o += q - p;
+        p = ff ? q + 1 : n;                                         // and the 00 after it is not
+    }
+    return o;
 }
 
 // Host path: all scans of a parsed file, in file order.

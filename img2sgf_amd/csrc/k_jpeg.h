@@ -23,12 +23,11 @@ struct JpgDesc {
     unsigned short q[3][64];    // quantisation tables of the components, natural order
 };
 
-// ---- entropy decoding on the device: one lane per file runs the decoder of jpeg_host.h (the same source, compiled
-// for the device) over the file's scans in order.  A Huffman stream is serial -- every symbol's position depends on the one
-// before -- and a lane needs a few hundred cycles per symbol (table lookups are dependent loads), so ONE file takes tens of
-// milliseconds; the device wins on batches: a pass of 256 files keeps 256 lanes busy for the time the slowest file takes,
-// where the host path spreads the files over at most 16 threads.  Restart intervals and the independent scans of a
-// progressive file would add lanes per file; not used yet.
+// ---- entropy decoding on the device, serial form: one lane per file runs the decoder of jpeg_host.h (the same
+// source, compiled for the device) over the file's scans in order.  A lane needs ~3 700 cycles per symbol (three or four
+// dependent global loads each), 0.8 s for a 220 KB file: 5-70 x slower than the host threads on passes of 16-256 files
+// (profiles/r02_e_jpeg_entropy_rate_lanes.txt).  It is kept for the files the parallel decoder (k_jpeg_entropy.h) does not
+// take -- progressive ones -- when everything is to stay on the device (i2s_params.jpeg_entropy_device = 2).
 struct JpgHuffScan {
     int ns, ci[3], td[3], ta[3], ss, se, ah, al, dri;
     int tab_dc[4], tab_ac[4];     // indices into the pass's table pool (-1: not defined at this scan)
@@ -37,10 +36,11 @@ struct JpgHuffScan {
 struct JpgHuffImg {
     JpegFrameView f;
     int scan0, nscans;
+    int slot;                     // where the verdict goes
     int16_t* coef[3];
 };
 
-// grid (ceil(nb / 64)), block 64.  status[i] = JPG_OK / JPG_BAD.
+// grid (ceil(nb / 64)), block 64.  status[imgs[i].slot] = JPG_OK / JPG_BAD.
 __global__ __launch_bounds__(64) void k_jpeg_huffman(const JpgHuffImg* __restrict__ imgs, const JpgHuffScan* __restrict__ scans,
                                                      const JpegHuff* __restrict__ tabs, const uint8_t* __restrict__ bytes, int nb,
                                                      int* __restrict__ status)
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void k_jpeg_huffman(const JpgHuffImg* __restric
         v.data = bytes + hs.off; v.len = hs.len;
         rc = jpg_decode_scan_view(im.f, v, coef);
     }
-    status[i] = rc;
+    status[im.slot] = rc;
 }
 
 // One pass of the LL&M inverse DCT over 8 values; SHIFT = 11 (columns) or 18 (rows).

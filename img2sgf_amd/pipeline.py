@@ -43,7 +43,7 @@ class Params:
     contrast: Optional[int] = None     # 0..100: ImageEnhance.Contrast on the device (img2sgf.py:141-144); None = input is already enhanced
     brightness: Optional[int] = None   # 0..100: ImageEnhance.Brightness on the device (:146-149)
     schedule: bool = False             # ragged batches larger than one device pass: form the passes over images sorted by area
-    jpeg_entropy_device: bool = False  # detect_jpeg: Huffman decoding on the device (one lane per file) instead of host threads
+    jpeg_entropy_device: int = 1       # detect_jpeg, Huffman decoding: 0 host threads, 1 sequential files on the device, 2 all on the device
 
     def to_c(self, inputs_on_device=False):
         p = I2sParams()
@@ -61,7 +61,7 @@ class Params:
         p.contrast = -1 if self.contrast is None else int(self.contrast)
         p.brightness = -1 if self.brightness is None else int(self.brightness)
         p.schedule = 1 if self.schedule else 0
-        p.jpeg_entropy_device = 1 if self.jpeg_entropy_device else 0
+        p.jpeg_entropy_device = int(self.jpeg_entropy_device)
         return p
 
 
@@ -123,6 +123,21 @@ def _detection_from_result(r: I2sResult) -> Detection:
         detected_board=det, full_board=full,
         stone_brightnesses=np.ctypeslib.as_array(r.brightness)[:r.n_stones].copy() if ready else np.zeros(0),
         num_black_stones=r.n_black, num_white_stones=r.n_white, side_to_move=r.side_to_move)
+
+
+class _LazyShapes:
+    """(h, w) of the files of the last pass, parsed on first use (fetch_source / fetch_plane need them, a bare detect does not)."""
+
+    def __init__(self, det, blobs):
+        self._det, self._blobs, self._shapes = det, list(blobs), None
+
+    def __getitem__(self, i):
+        if self._shapes is None:
+            self._shapes = [self._det.jpeg_info(b)[1::-1] for b in self._blobs]
+        return self._shapes[i]
+
+    def __len__(self):
+        return len(self._blobs)
 
 
 def jpeg_info(data: bytes, lib=None):
@@ -216,9 +231,19 @@ class Detector:
         """(w, h, components) of a JPEG the device path can decode; raises I2sError (unsupported / invalid) otherwise."""
         return jpeg_info(data, self.lib)
 
+    def jpeg_last_rounds(self) -> int:
+        """Rounds the parallel entropy decoder's iteration took in the last pass (0 = it did not run)."""
+        return int(self.lib.dll.i2s_jpeg_last_rounds(self._ctx))
+
+    def jpeg_last_timing(self):
+        """Host wall times of the last detect_jpeg call, ms: parsing, entropy stage host work, entropy stage device wait, whole call."""
+        ms = (C.c_float * 4)()
+        self._check(self.lib.dll.i2s_jpeg_last_timing(self._ctx, ms))
+        return list(ms)
+
     def detect_jpeg(self, blobs: Sequence[bytes], params: Optional[Params] = None, full=True, xforms=None):
         """blobs: the bytes of JPEG files (8-bit, Huffman-coded, sequential or progressive).  Image.open(path).convert("RGB") (img2sgf.py:651) happens on the device
-        (Huffman stage on the host), bit-exact with Pillow; then as detect_batch (xforms / Params.contrast / .brightness apply
+        (Huffman stage per Params.jpeg_entropy_device), bit-exact with Pillow; then as detect_batch (xforms / Params.contrast / .brightness apply
         to the decoded image).  Raises I2sError("parameter outside the supported envelope") for CMYK, arithmetic-coded
         and other flavours -- decode those with Pillow and call detect_batch."""
         params = params or Params()
@@ -235,13 +260,17 @@ class Detector:
                 xf[i].crop[:] = [int(v) for v in crop]
             shapes = [(x.crop[3] - x.crop[1], x.crop[2] - x.crop[0]) for x in xf]
         else:
-            shapes = [self.jpeg_info(b)[1::-1] for b in blobs]
+            shapes = None                       # frame sizes: read from the files only where (and when) they are needed
         p = params.to_c()
         self._check(self.lib.dll.i2s_detect_jpeg_batch(self._ctx, B, arr, lens, xf, C.byref(p), boards, res))
         n_last = (B - 1) % self.max_batch + 1 if B else 0
         if params.schedule and B > self.max_batch:
+            if shapes is None:
+                shapes = [self.jpeg_info(b)[1::-1] for b in blobs]
             order = sorted(range(B), key=lambda i: shapes[i][0] * shapes[i][1])
             self._last_shapes = [shapes[i] for i in order[B - n_last:]]
+        elif shapes is None:
+            self._last_shapes = _LazyShapes(self, blobs[B - n_last:])
         else:
             self._last_shapes = shapes[B - n_last:]
         if not full:

@@ -131,9 +131,11 @@ typedef struct i2s_params {
      * images sorted by area, so that a pass's tile grids (sized for its largest image) are not mostly empty; results are
      * returned in input order.  The "last pass" the fetch / classify calls refer to is then the pass of the largest images. */
     int32_t schedule;
-    /* i2s_detect_jpeg_batch: 0 (default) = Huffman decoding on host threads; 1 = on the device, one lane per file (the same
-     * decoder source, bit-exact; a lane decodes far slower than a core, so it only pays for passes of thousands of files:
-     * DESIGN.md 6c holds the measured rates) */
+    /* i2s_detect_jpeg_batch, where the Huffman decoding runs.  1 (default): sequential files on the device, parallel inside
+     * every scan (csrc/k_jpeg_entropy.h); progressive files, and files whose entropy-coded data hold anything but stuffed
+     * FF00 bytes and RSTn markers, on host threads meanwhile.  0: every file on host threads (round 1's path).  2: as 1, but
+     * the files the parallel decoder does not take run on the device too, one lane per file (slow: DESIGN.md 6c).  The three
+     * give the same coefficients, bit for bit, and refuse the same files. */
     int32_t jpeg_entropy_device;
 } i2s_params;
 
@@ -215,7 +217,7 @@ int  i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* img,
 
 /* JPEG input: Image.open(path).convert("RGB") (img2sgf.py:651) for 8-bit Huffman JPEGs, sequential or
  * progressive (grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, any scan script), bit-exact with Pillow / libjpeg-turbo: marker parsing
- * on the host, entropy decoding on host threads (i2s_params.jpeg_entropy_device = 1: on the device, one lane per file), dequantisation +
+ * on the host, entropy decoding on the device for sequential files (i2s_params.jpeg_entropy_device), dequantisation +
  * inverse DCT + chroma upsampling + colour conversion on the device, then the ordinary path (xf
  * and the contrast / brightness step of p apply to the decoded image).  I2S_E_UNSUPPORTED for any other flavour (arithmetic
  * coding, CMYK, RGB-coded, 12-bit, lossless): nothing is approximated, decode those elsewhere and use i2s_detect_batch(_xf).
@@ -223,6 +225,13 @@ int  i2s_detect_batch_xf(i2s_ctx* ctx, int B, const uint8_t* const* img,
 int  i2s_jpeg_info(const uint8_t* data, size_t len, int* w, int* h, int* channels);
 int  i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* jpeg, const size_t* len,
                            const i2s_xform* xf, const i2s_params* p, i2s_board* boards, i2s_result* full);
+/* Rounds the parallel entropy decoder's iteration took in the last pass of the last i2s_detect_jpeg_batch call (0: it did not
+ * run -- mode 0, or no sequential file in the pass).  Diagnostic. */
+int  i2s_jpeg_last_rounds(const i2s_ctx* ctx);
+/* Host-side wall times of the last i2s_detect_jpeg_batch call, ms: [0] marker parsing, [1] the entropy stage's host work
+ * (removing the byte stuffing and building the records, or the Huffman decoding itself on host threads), [2] waiting for the
+ * device inside the entropy stage, [3] the whole call.  Diagnostic. */
+int  i2s_jpeg_last_timing(const i2s_ctx* ctx, float ms[4]);
 
 /* Re-run the stone classifier on the images of the LAST pass of the last detect call
  * (first..first+n) with p->black_threshold / p->align_*; circles, lines and grid are reused. */

@@ -220,16 +220,18 @@ def test_jpeg_decode_matches_pillow(lib):
     blobs.append(buf.getvalue())
     refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
     det = Detector(0, len(blobs), 300, 260, lib=lib)
-    dets = det.detect_jpeg(blobs, Params(jpeg_entropy_device=True), full=True)
+    dets = det.detect_jpeg(blobs, Params(jpeg_entropy_device=2), full=True)
     for k, (d, r) in enumerate(zip(dets, refs)):
         np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d" % k)
         parity.compare_detection(d, opipe.process_image(r))
-    # the same decoder source on host threads (the default) instead of one lane per file
-    det.detect_jpeg(blobs, Params(), full=False)
-    for k, r in enumerate(refs):
-        np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d, host entropy" % k)
+    # Huffman decoding on host threads (mode 0) and the default split (sequential files on the device, progressive on the host)
+    for mode in (0, 1):
+        det.detect_jpeg(blobs, Params(jpeg_entropy_device=mode), full=False)
+        for k, r in enumerate(refs):
+            np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d, entropy mode %d" % (k, mode))
+        assert (det.jpeg_last_rounds() > 0) == (mode == 1)         # the parallel decoder ran (and needed more than the first round)
     with pytest.raises(I2sError):
-        det.detect_jpeg([blobs[0][:len(blobs[0]) // 2] + b"\xff\xd9"], Params(jpeg_entropy_device=True), full=False)      # truncated entropy data, device path
+        det.detect_jpeg([blobs[0][:len(blobs[0]) // 2] + b"\xff\xd9"], Params(jpeg_entropy_device=2), full=False)      # truncated entropy data, device path
     buf = io.BytesIO()
     Image.fromarray(np.zeros((24, 24, 4), np.uint8), "CMYK").save(buf, "JPEG")
     with pytest.raises(I2sError):

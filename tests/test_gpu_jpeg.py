@@ -26,9 +26,10 @@ def _blob(name):
         return f.read()
 
 
-@pytest.fixture(params=[False, True], ids=["entropy-host", "entropy-device"])
+@pytest.fixture(params=[0, 1, 2], ids=["entropy-host", "entropy-device", "entropy-device-all"])
 def on_device(request):
-    """i2s_params.jpeg_entropy_device: Huffman decoding on host threads (default) or one lane per file on the device."""
+    """i2s_params.jpeg_entropy_device: Huffman decoding on host threads; sequential files in parallel on the device (default);
+    those plus one lane per file for the progressive ones."""
     return request.param
 
 
@@ -130,7 +131,7 @@ def test_multi_pass_scheduled_jpeg_batch():
     want = [bytes(b) for b in det.detect_jpeg(blobs, Params(), full=False)]
     det.close()
     det = Detector(0, 4, 310, 310)
-    for sched, dev in ((False, False), (True, False), (False, True), (True, True)):
+    for sched, dev in ((False, 0), (True, 0), (False, 1), (True, 1), (True, 2)):
         got = det.detect_jpeg(blobs, Params(schedule=sched, jpeg_entropy_device=dev), full=False)
         assert [bytes(b) for b in got] == want
     det.close()
