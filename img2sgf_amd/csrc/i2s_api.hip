@@ -732,11 +732,10 @@ static int jpeg_bad(i2s_ctx* ctx, int k)
     return I2S_E_INVALID;
 }
 
-static int jpeg_on_host(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const int* order, std::vector<int16_t>& coef,
-                        size_t ncoef)
+// The serial decoder on the host threads for `list` (no HIP calls: it may run beside the device work); -1 or the input index
+// of a corrupt file.  coef must already hold ncoef bytes.
+static int jpeg_host_decode(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const int* order, std::vector<int16_t>& coef)
 {
-    if (list.empty()) return I2S_OK;
-    if (coef.size() < ncoef / sizeof(int16_t)) coef.resize(ncoef / sizeof(int16_t));
     const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
     std::atomic<int> bad(-1);
     rc_parallel_for((int)list.size(), [&](int n) {
@@ -749,7 +748,12 @@ static int jpeg_on_host(i2s_ctx* ctx, const std::vector<int>& list, const std::v
         }
         if (jpg_decode_scan(f, cp) != JPG_OK) bad.store(order[i]);
     });
-    if (bad.load() >= 0) return jpeg_bad(ctx, bad.load());
+    return bad.load();
+}
+
+static int jpeg_host_upload(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const std::vector<int16_t>& coef)
+{
+    const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
     for (int i : list)
         for (int c = 0; c < files[i].ncomp; c++) {
             const size_t off = (size_t)(ctx->h_jd[i].coef[c] - d0);
@@ -972,18 +976,23 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
 static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& files, const uint8_t* const* jpeg, const size_t* len, const int* order,
                              int mode, size_t ncoef, std::vector<int16_t>& coef)
 {
-    std::vector<int> all(nb), par, host, lanes;
+    std::vector<int> par, host, lanes, late;
     ctx->je_rounds = 0;
     const double t_in = now_ms();
     const float w_in = ctx->jpeg_ms[2];
     struct Span { i2s_ctx* c; double t; float w; ~Span() { c->jpeg_ms[1] += (float)(now_ms() - t) - (c->jpeg_ms[2] - w); } } span{ctx, t_in, w_in};
-    for (int i = 0; i < nb; i++) all[i] = i;
     I2S_HIP(hipMemsetAsync(ctx->d_jpg, 0, ncoef, ctx->stream));                      // coefficients start at zero
-    if (mode == 0) return jpeg_on_host(ctx, all, files, order, coef, ncoef);
     I2S_HIP(hipMemsetAsync(ctx->d_jstatus, 0, (size_t)nb * sizeof(int), ctx->stream));
-    std::vector<int>& rest = mode == 1 ? host : lanes;
-    for (int i = 0; i < nb; i++) (files[i].progressive ? rest : par).push_back(i);
+    for (int i = 0; i < nb; i++) (mode == 0 ? host : (files[i].progressive ? (mode == 1 ? host : lanes) : par)).push_back(i);
+    // the host threads start on their files at once and run beside the device's
+    int host_bad = -1;
+    std::thread host_job;
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{host_job};
+    auto need_coef = [&]() { if (coef.size() < ncoef / sizeof(int16_t)) coef.resize(ncoef / sizeof(int16_t)); };     // the host copy: 15 x the file bytes
+    if (!host.empty()) need_coef();
+    if (!host.empty()) host_job = std::thread([&]() { host_bad = jpeg_host_decode(ctx, host, files, order, coef); });
     bool converged = true;
+    std::vector<int>& rest = mode == 2 ? lanes : late;          // files the parallel decoder hands back
     int rc = jpeg_parallel(ctx, par, rest, files, order, &converged);
     if (rc) return rc;
     if (!converged) {
@@ -993,7 +1002,12 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     std::vector<uint8_t> bytes;
     rc = jpeg_lanes(ctx, lanes, files, jpeg, len, order, bytes);
     if (rc) return rc;
-    rc = jpeg_on_host(ctx, host, files, order, coef, ncoef);                          // overlaps the kernels launched above
+    if (host_job.joinable()) host_job.join();
+    if (host_bad < 0 && !late.empty()) { need_coef(); host_bad = jpeg_host_decode(ctx, late, files, order, coef); }
+    if (host_bad >= 0) return jpeg_bad(ctx, host_bad);
+    rc = jpeg_host_upload(ctx, host, files, coef);
+    if (rc) return rc;
+    rc = jpeg_host_upload(ctx, late, files, coef);
     if (rc) return rc;
     I2S_HIP(hipMemcpyAsync(ctx->h_jstatus, ctx->d_jstatus, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     const double t0 = now_ms();

@@ -1,7 +1,7 @@
-// Baseline JPEG front end: marker parsing and Huffman entropy decoding on the host -- a serial bit stream per
+// JPEG front end: marker parsing, and the serial form of the Huffman entropy decoding -- one bit stream per
 // scan -- into quantised DCT coefficient blocks.  Everything after that (dequantisation, inverse DCT, chroma upsampling,
-// colour conversion: csrc/k_jpeg.h) runs on the device.  The reference reaches the same pixels through
-// PIL.Image.open(path).convert("RGB") (img2sgf.py:651), i.e. libjpeg-turbo with its defaults (JDCT_ISLOW, fancy upsampling);
+// colour conversion: csrc/k_jpeg.h) runs on the device, and so does the entropy decoding of sequential files
+// (k_jpeg_entropy.h).  The reference reaches the same pixels through PIL.Image.open(path).convert("RGB") (img2sgf.py:651), i.e. libjpeg-turbo with its defaults (JDCT_ISLOW, fancy upsampling);
 // this file and k_jpeg.h restate exactly that decoder for 8-bit Huffman JPEGs, sequential (SOF0 / SOF1) and progressive (SOF2,
 // spectral selection + successive approximation), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, any scan script that ends with
 // coefficients 0..9 of every component fully refined (Al = 0): Pillow leaves libjpeg's do_block_smoothing on, and
@@ -16,9 +16,10 @@
 
 #include <vector>
 
-// The entropy decoder below (bit reader, Huffman symbols, sequential and progressive block decoding) is written once and
-// compiled twice: for the host (round 1's path: one file per host thread) and for the device (k_jpeg_huffman, k_jpeg.h: one
-// file per lane).  The marker parser stays host-only.
+// The serial entropy decoder below (bit reader, Huffman symbols, sequential and progressive block decoding) is written once and
+// compiled twice: for the host (one file per host thread: progressive files, and every file when i2s_params.jpeg_entropy_device
+// is 0) and for the device (k_jpeg_huffman, k_jpeg.h: one file per lane; jpeg_entropy_device 2).  Sequential files are normally
+// decoded by k_jpeg_entropy.h, parallel inside each scan; this decoder is its yardstick.  The marker parser stays host-only.
 #if defined(__HIPCC__) || defined(HIPEMU)
 #define I2S_HD __host__ __device__
 #else

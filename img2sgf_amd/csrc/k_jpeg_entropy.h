@@ -7,15 +7,15 @@
 // Schmidt ("Accelerating JPEG decompression on GPUs", 2021) describe it, restated as a fixed-point iteration:
 //
 //   * the host removes the byte stuffing (FF00 -> FF) and cuts the scan at its RSTn markers into SEGMENTS (restart
-//     intervals; a scan without DRI is one segment) -- one memchr-speed copy, jpg_destuff below;
+//     intervals; a scan without DRI is one segment) -- one memchr-speed copy on the host threads (jpg_destuff, jpeg_host.h);
 //   * a segment is cut into SUBSEQUENCES of 1024 bits, one per thread.  The decoder state between two code words is
 //     (bit position p, zigzag index z inside the block, block index u inside the MCU).  E[i], the state at the first code-word
 //     boundary at or after the start of subsequence i, is exact for i = 0 (0, 0, 0) and GUESSED (start bit, 0, 0) elsewhere;
 //   * k_je_sync, round r: thread i decodes subsequence i from E[i] up to the first boundary at or beyond its end -- X_i(E[i]) --
 //     and stores that as E[i+1] if it differs, which schedules thread i+1 for round r+1.  When a round changes nothing,
 //     E[i+1] = X_i(E[i]) holds for every i and E[0] is exact, so every E[i] is exact by induction: the result does NOT
-//     depend on the streams resynchronising, only the number of rounds does (2-4 on photographs and diagrams; a long run of
-//     identical blocks can hold a false parse in step with the true one and costs one round per subsequence of the run);
+//     depend on the streams resynchronising, only the number of rounds does (3-4 on photographs, 7-9 on rendered diagrams: a
+//     run of identical blocks can hold a false parse in step with the true one and costs one round per subsequence of the run);
 //   * each run also counts the blocks it completed and sums the DC differences per component; k_je_scan turns them into the
 //     block ordinal and the DC predictors at the start of every subsequence (one wave per segment, running sums);
 //   * k_je_write decodes every subsequence once more from its exact state and stores the coefficients where they belong.

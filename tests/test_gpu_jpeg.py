@@ -157,3 +157,73 @@ def test_streamed_jpeg_batch():
     got = sd.detect_jpeg(blobs, Params(contrast=70, brightness=50))
     sd.close()
     assert [bytes(b) for b in got] == want
+
+
+def _entropy_span(blob):
+    """[first, last) byte of the entropy-coded data of a single-scan file (after the SOS header, before the EOI)."""
+    i = blob.index(b"\xff\xda")
+    return i + 2 + ((blob[i + 2] << 8) | blob[i + 3]), len(blob) - 2
+
+
+def test_damaged_entropy_data_same_outcome_on_every_path():
+    """Bytes of the entropy-coded data overwritten at random, or a piece cut out: the serial decoder on the host threads is the
+    yardstick -- the parallel decoder must refuse exactly the files it refuses and produce the very same pixels for the ones
+    it lets through (a damaged stream mostly still decodes, to garbage)."""
+    rng = np.random.default_rng(4242)
+    det = Detector(0, 1, 420, 420)
+    refused = agreed = 0
+    for trial in range(120):
+        h, w = int(rng.integers(40, 400)), int(rng.integers(40, 400))
+        src = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", "ex%d.jpg" % int(rng.integers(6, 18))))
+        img = np.ascontiguousarray(src[100:100 + h, 100:100 + w]) if trial % 3 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        kw = dict(quality=int(rng.integers(30, 96)), subsampling=int(rng.integers(0, 3)))
+        if trial % 4 == 1:
+            kw["restart_marker_rows"] = int(rng.integers(1, 3))
+        elif trial % 4 == 2:
+            kw["restart_marker_blocks"] = int(rng.integers(2, 40))
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", **kw)
+        blob = bytearray(buf.getvalue())
+        a, b = _entropy_span(blob)
+        if trial % 5 == 4:                                            # a piece missing
+            c = int(rng.integers(a, b - 8))
+            del blob[c:c + int(rng.integers(1, 64))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                blob[int(rng.integers(a, b))] = int(rng.integers(0, 255))     # never a new 0xFF: no new markers
+        blob = bytes(blob)
+        out = []
+        for mode in (0, 1, 2):
+            try:
+                det.detect_jpeg([blob], Params(jpeg_entropy_device=mode), full=False)
+                out.append(det.fetch_source(0, 3).copy())
+            except I2sError:
+                out.append(None)
+        assert (out[0] is None) == (out[1] is None) == (out[2] is None), "trial %d: refused by some paths only" % trial
+        if out[0] is None:
+            refused += 1
+        else:
+            np.testing.assert_array_equal(out[1], out[0], err_msg="trial %d" % trial)
+            np.testing.assert_array_equal(out[2], out[0], err_msg="trial %d" % trial)
+            agreed += 1
+    det.close()
+    assert refused > 5 and agreed > 5, (refused, agreed)
+
+
+def test_large_photograph_many_subsequences():
+    """A 2048 x 1536 noisy image: ~1 MB of entropy-coded data, thousands of subsequences per scan; and the same with a restart
+    interval of one MCU (tens of thousands of one-subsequence segments)."""
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:1536, 0:2048]
+    img = np.stack([(xx * 3 + yy) % 256, (yy * 2 + xx // 3) % 256, (xx + yy * 5) % 256], -1).astype(np.uint8)
+    img[400:1200, 300:1500] = rng.integers(0, 256, (800, 1200, 3), dtype=np.uint8)
+    det = Detector(0, 1, 2048, 1536)
+    for kw in (dict(quality=92, subsampling=2), dict(quality=85, subsampling=0, restart_marker_blocks=1), dict(quality=60, subsampling=1, optimize=True)):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", **kw)
+        blob = buf.getvalue()
+        want = np.array(Image.open(io.BytesIO(blob)).convert("RGB"))
+        det.detect_jpeg([blob], Params(), full=False)
+        assert det.jpeg_last_rounds() > 0
+        np.testing.assert_array_equal(det.fetch_source(0, 3), want)
+    det.close()

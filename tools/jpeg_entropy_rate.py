@@ -2,7 +2,8 @@
 """File bytes -> board records (i2s_detect_jpeg_batch end to end) by where the Huffman decoding runs
 (i2s_params.jpeg_entropy_device: 0 host threads, 1 sequential files in parallel on the device, 2 = 1 + progressive files one
 lane each), by pass size.  The 18 reference fixtures x 16 (four progressive ones among them), Pillow-encoded 1024x1024 diagrams
-and a blank page (the worst case for the parallel decoder's iteration count).  --lanes adds mode 2 (slow)."""
+and a blank page (the worst case for the parallel decoder's iteration count).  --lanes adds mode 2 (slow); --device-only runs
+mode 1 at 256 files per pass alone (for a kernel trace)."""
 import io
 import os
 import sys
@@ -33,6 +34,9 @@ Image.fromarray(np.full((1024, 1024, 3), 255, np.uint8)).save(b, "JPEG", quality
 blank = [b.getvalue()] * 64
 
 MODES = [(0, "host threads"), (1, "device")] + ([(2, "device + lanes")] if "--lanes" in sys.argv else [])
+if "--device-only" in sys.argv:                # for rocprofv3: the default path alone
+    MODES = [(1, "device")]
+PASSES = (256,) if "--device-only" in sys.argv else (16, 64, 256)
 
 
 def rate(blobs, mb, mode, size):
@@ -49,7 +53,7 @@ def rate(blobs, mb, mode, size):
 
 for name, blobs, size in (("18 fixtures x 16", fixtures, 1300), ("1024x1024 diagrams, q90", diagrams, 1024), ("blank 1024x1024 page", blank, 1024)):
     print("%s: %d files, %.1f MB" % (name, len(blobs), sum(len(b) for b in blobs) / 1e6))
-    for mb in (16, 64, 256):
+    for mb in PASSES:
         if mb > len(blobs):
             continue
         line, ref = "  pass of %3d files:" % mb, None
