@@ -11,6 +11,11 @@ def short(name):
     return re.sub(r"^void ", "", name).replace("i2s::", "")
 
 
+def q(name):
+    """CSV field: template arguments carry commas (k_circles_final<4096, 2048>)."""
+    return '"%s"' % name.replace('"', '""') if ("," in name or '"' in name) else name
+
+
 def main():
     db = sqlite3.connect(sys.argv[1])
     cur = db.cursor()
@@ -31,7 +36,7 @@ def main():
     lines = ["kernel,dispatches," + ",".join(n + "_per_dispatch" for n in names)]
     for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
         n = len(disp[k])
-        lines.append(k + "," + str(n) + "," + ",".join("%.6g" % (agg[k].get(c, 0.0) / n) for c in names))
+        lines.append(q(k) + "," + str(n) + "," + ",".join("%.6g" % (agg[k].get(c, 0.0) / n) for c in names))
     txt = "\n".join(lines)
     print(txt)
     if len(sys.argv) > 2:

@@ -12,6 +12,11 @@ def short(name):
     return name.replace("i2s::", "")
 
 
+def q(name):
+    """CSV field: template arguments carry commas (k_circles_final<4096, 2048>)."""
+    return '"%s"' % name.replace('"', '""') if ("," in name or '"' in name) else name
+
+
 def main():
     db = sqlite3.connect(sys.argv[1])
     cur = db.cursor()
@@ -26,7 +31,7 @@ def main():
     total = sum(a[1] for a in agg.values())
     lines = ["kernel,calls,total_us,avg_us,min_us,max_us,percent"]
     for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lines.append("%s,%d,%.1f,%.2f,%.2f,%.2f,%.2f" % (n, a[0], a[1] / 1e3, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3,
+        lines.append("%s,%d,%.1f,%.2f,%.2f,%.2f,%.2f" % (q(n), a[0], a[1] / 1e3, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3,
                                                          100.0 * a[1] / total))
     txt = "\n".join(lines)
     print(txt)
