@@ -72,6 +72,7 @@ struct i2s_ctx {
     uint8_t* h_jblob = nullptr;  // pinned: the destuffed entropy-coded bytes of a pass (grown on demand)
     size_t jblob_bytes = 0;
     int je_rounds = 0;           // rounds k_je_sync took in the last pass
+    int je_max_rounds = 2048;    // beyond this a pass is handed to the serial decoder (i2s_jpeg_set_max_rounds)
     float jpeg_ms[4] = {0, 0, 0, 0};     // last i2s_detect_jpeg_batch: parsing | entropy stage, host work | entropy stage, waiting for the device | whole call
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
@@ -818,7 +819,7 @@ static int jpeg_lanes(i2s_ctx* ctx, const std::vector<int>& list, const std::vec
     return I2S_OK;
 }
 
-constexpr int JE_MAX_ROUNDS = 2048;        // beyond this the pass is handed to the host decoder (never seen; a crafted stream could)
+constexpr int JE_MAX_ROUNDS = 1 << 16;     // room in the flag array; the context's je_max_rounds (2048) is the working limit
 constexpr int JE_MAX_SEGS = 1 << 16;       // restart intervals per scan handled on the device
 
 // Sequential files of `list`, parallel inside each scan.  Files whose entropy-coded data hold more than stuffed bytes and RSTn
@@ -939,7 +940,7 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     I2S_HIP(hipMemcpyAsync(D + o_scan, scans.data(), scans.size() * sizeof(JeScan), hipMemcpyHostToDevice, st));
     I2S_HIP(hipMemcpyAsync(D + o_seg, segs.data(), segs.size() * sizeof(JeSeg), hipMemcpyHostToDevice, st));
     I2S_HIP(hipMemcpyAsync(D + o_bs, blk_scan.data(), blk_scan.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    I2S_HIP(hipMemsetAsync(D + o_flag, 0, (JE_MAX_ROUNDS + 4) * sizeof(uint32_t), st));
+    I2S_HIP(hipMemsetAsync(D + o_flag, 0, ((size_t)ctx->je_max_rounds + 16) * sizeof(uint32_t), st));
     I2S_HIP(hipMemsetAsync(D + o_acc, 0, (size_t)ntot * sizeof(JeAcc), st));
     const JeScan* d_scans = reinterpret_cast<const JeScan*>(D + o_scan);
     const JeSeg* d_segs = reinterpret_cast<const JeSeg*>(D + o_seg);
@@ -956,14 +957,15 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     uint32_t round = 0;
     int burst = 3;
     for (;;) {
-        for (int n = 0; n < burst; n++, round++)
+        const int left = ctx->je_max_rounds - (int)round;
+        if (left <= 0) { *converged = false; return I2S_OK; }
+        for (int n = 0; n < std::min(burst, left); n++, round++)
             hipLaunchKernelGGL(k_je_sync, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_tabs, d_blob, d_E, d_stamp, d_acc, d_flag, round);
         I2S_HIP(hipMemcpyAsync(ctx->h_jflag, d_flag + (round - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         const double t0 = now_ms();
         I2S_HIP(hipStreamSynchronize(st));
         ctx->jpeg_ms[2] += (float)(now_ms() - t0);
         if (*ctx->h_jflag == 0) break;
-        if (round >= (uint32_t)JE_MAX_ROUNDS) { *converged = false; return I2S_OK; }
         burst = round < 16 ? 2 : 8;
     }
     ctx->je_rounds = (int)round;
@@ -1019,6 +1021,13 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
 }
 
 extern "C" int i2s_jpeg_last_rounds(const i2s_ctx* ctx) { return ctx ? ctx->je_rounds : 0; }
+
+extern "C" int i2s_jpeg_set_max_rounds(i2s_ctx* ctx, int rounds)
+{
+    if (!ctx || rounds < 1 || rounds > JE_MAX_ROUNDS - 16) return I2S_E_INVALID;
+    ctx->je_max_rounds = rounds;
+    return I2S_OK;
+}
 
 extern "C" int i2s_jpeg_last_timing(const i2s_ctx* ctx, float ms[4])
 {

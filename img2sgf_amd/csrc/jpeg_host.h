@@ -292,9 +292,10 @@ struct JpegBits {
     {
         if (overrun()) return false;
         acc = 0; cnt = 0; real_bits = 0; used_bits = 0;
-        if (!hit_marker) {                                           // skip fill bytes up to the marker
+        if (!hit_marker) {                                           // skip what is left of the interval, up to the marker
             while (p + 1 < n && !(d[p] == 0xFF && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7)) p++;
         }
+        while (p + 2 < n && d[p] == 0xFF && d[p + 1] == 0xFF) p++;   // fill bytes in front of the marker (B.1.1.2): any number of FF
         if (p + 1 >= n || d[p] != 0xFF || d[p + 1] < 0xD0 || d[p + 1] > 0xD7) return false;
         p += 2;
         hit_marker = false;

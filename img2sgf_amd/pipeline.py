@@ -235,6 +235,10 @@ class Detector:
         """Rounds the parallel entropy decoder's iteration took in the last pass (0 = it did not run)."""
         return int(self.lib.dll.i2s_jpeg_last_rounds(self._ctx))
 
+    def jpeg_set_max_rounds(self, rounds: int):
+        """Limit of the parallel entropy decoder's iteration; a pass that needs more goes to the serial decoder."""
+        self._check(self.lib.dll.i2s_jpeg_set_max_rounds(self._ctx, int(rounds)))
+
     def jpeg_last_timing(self):
         """Host wall times of the last detect_jpeg call, ms: parsing, entropy stage host work, entropy stage device wait, whole call."""
         ms = (C.c_float * 4)()

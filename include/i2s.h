@@ -228,6 +228,9 @@ int  i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* jpeg, cons
 /* Rounds the parallel entropy decoder's iteration took in the last pass of the last i2s_detect_jpeg_batch call (0: it did not
  * run -- mode 0, or no sequential file in the pass).  Diagnostic. */
 int  i2s_jpeg_last_rounds(const i2s_ctx* ctx);
+/* The iteration's limit (default 2048 rounds; a pass that needs more -- a stream of identical blocks tens of thousands of
+ * blocks long, or a crafted one -- is decoded by the serial decoder instead: host threads in mode 1, lanes in mode 2). */
+int  i2s_jpeg_set_max_rounds(i2s_ctx* ctx, int rounds);
 /* Host-side wall times of the last i2s_detect_jpeg_batch call, ms: [0] marker parsing, [1] the entropy stage's host work
  * (removing the byte stuffing and building the records, or the Huffman decoding itself on host threads), [2] waiting for the
  * device inside the entropy stage, [3] the whole call.  Diagnostic. */

@@ -230,6 +230,13 @@ def test_jpeg_decode_matches_pillow(lib):
         for k, r in enumerate(refs):
             np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d, entropy mode %d" % (k, mode))
         assert (det.jpeg_last_rounds() > 0) == (mode == 1)         # the parallel decoder ran (and needed more than the first round)
+    # a pass beyond the iteration's limit is handed to the serial decoder
+    det.jpeg_set_max_rounds(1)
+    det.detect_jpeg(blobs, Params(), full=False)
+    assert det.jpeg_last_rounds() == 0
+    for k, r in enumerate(refs):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d, one round allowed" % k)
+    det.jpeg_set_max_rounds(2048)
     with pytest.raises(I2sError):
         det.detect_jpeg([blobs[0][:len(blobs[0]) // 2] + b"\xff\xd9"], Params(jpeg_entropy_device=2), full=False)      # truncated entropy data, device path
     buf = io.BytesIO()

@@ -227,3 +227,45 @@ def test_large_photograph_many_subsequences():
         assert det.jpeg_last_rounds() > 0
         np.testing.assert_array_equal(det.fetch_source(0, 3), want)
     det.close()
+
+
+def _with_fill_bytes(blob):
+    """An extra FF in front of every RSTn marker of the entropy-coded data: legal fill bytes (T.81 B.1.1.2), libjpeg skips them."""
+    a, b = _entropy_span(blob)
+    out, n = bytearray(blob[:a]), 0
+    i = a
+    while i < b:
+        if blob[i] == 0xFF and 0xD0 <= blob[i + 1] <= 0xD7:
+            out += b"\xff" * (1 + n % 3)
+            n += 1
+        out.append(blob[i])
+        i += 1
+    return bytes(out + blob[b:]), n
+
+
+def test_fill_bytes_and_iteration_limit(on_device):
+    """Files the parallel decoder hands back: fill bytes in front of restart markers (the serial decoder takes them), and a pass
+    that exceeds the iteration's limit (set to one round here)."""
+    rng = np.random.default_rng(5150)
+    src = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", "ex8.jpg"))
+    blobs = []
+    for kw in (dict(quality=80, subsampling=2, restart_marker_rows=1), dict(quality=60, subsampling=0, restart_marker_blocks=9), dict(quality=90, subsampling=1)):
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(src[50:350, 80:420])).save(buf, "JPEG", **kw)
+        blobs.append(buf.getvalue())
+    filled, n = _with_fill_bytes(blobs[0])
+    assert n > 5
+    filled2, _ = _with_fill_bytes(blobs[1])
+    files = [filled, blobs[2], filled2, blobs[0]]
+    refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in files]
+    det = Detector(0, len(files), 420, 420)
+    det.detect_jpeg(files, Params(jpeg_entropy_device=on_device), full=False)
+    for k, r in enumerate(refs):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d" % k)
+    assert (det.jpeg_last_rounds() > 0) == (on_device > 0)
+    det.jpeg_set_max_rounds(1)
+    det.detect_jpeg(files, Params(jpeg_entropy_device=on_device), full=False)
+    for k, r in enumerate(refs):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d, one round allowed" % k)
+    assert det.jpeg_last_rounds() == 0
+    det.close()
