@@ -489,10 +489,10 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                            ctx->d_est_keys, est_count(ctx));
         I2S_SEG(11);
         if (g.est_cap <= EST_UNIT)
-            hipLaunchKernelGGL((k_circles_final<EST_UNIT, VCIRC_UNIT>), dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys,
+            hipLaunchKernelGGL((k_circles_final<EST_UNIT, VCIRC_UNIT, true>), dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys,
                                est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
         else
-            hipLaunchKernelGGL((k_circles_final<EST_UNIT * CAP_SCALE_MAX, VCIRC_UNIT * CAP_SCALE_MAX>), dim3(nb * NVAR), dim3(FIN_THREADS),
+            hipLaunchKernelGGL((k_circles_final<EST_UNIT * CAP_SCALE_MAX, VCIRC_UNIT * CAP_SCALE_MAX, false>), dim3(nb * NVAR), dim3(FIN_THREADS),
                                0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc,
                                vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));

@@ -495,13 +495,18 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
 }
 
 constexpr int FIN_THREADS = 1024;
+constexpr int FIN_BUCKETS = 4096;      // hash buckets of the RemoveOverlaps neighbour grid (HASH instantiation)
 
 // grid (nb * NVAR), block FIN_THREADS.  Sorts the estimates (OpenCV's cmpAccum order), runs RemoveOverlaps (keep a circle
 // iff it is at least min_dist from every circle already kept) and writes circles (x, y, r) in output order.
 // vcirc[(bv * g.vcirc_cap + i) * 3], vcount[bv]; overflow[b] is set when a capacity was exceeded.
 // ECAP / VCAP: compile-time capacities of the LDS arrays (>= g.est_cap / g.vcirc_cap); the host launches the instantiation that
 // fits the context's capacities, so that 1024 x 1024 contexts keep the small footprint (several workgroups per CU).
-template <int ECAP, int VCAP>
+// HASH: candidates are also chained into a grid of min_dist-sized cells (hashed into FIN_BUCKETS LDS list heads), so that
+// RemoveOverlaps looks at the 3 x 3 cells around a candidate instead of at every earlier one: the Gaussian variants of a diagram
+// yield ~750 estimates, and the all-pairs sweep was 70 % of this kernel's time.  The large-capacity instantiation has no LDS
+// left for the grid and keeps the sweep.
+template <int ECAP, int VCAP, bool HASH>
 __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned long long* __restrict__ est_keys,
                                                        const int* __restrict__ est_count, const int* __restrict__ cent_count,
                                                        float min_dist, int min_r,
@@ -509,8 +514,10 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
 {
     __shared__ unsigned long long s_key[ECAP];
     __shared__ short s_kx[VCAP];
-    __shared__ int s_scan[FIN_THREADS];
+    __shared__ int s_wsum[FIN_THREADS / 64];
     __shared__ int s_flag[3];
+    __shared__ int s_head[HASH ? FIN_BUCKETS : 1];
+    __shared__ unsigned short s_next[HASH ? ECAP : 1];
     const int bv = blockIdx.x;
     const int b = bv / NVAR;
     const int tid = threadIdx.x;
@@ -522,16 +529,16 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     for (int i = tid; i < np2; i += FIN_THREADS) s_key[i] = i < n ? est_keys[(size_t)bv * g.est_cap + i] : ~0ull;
+    if (HASH) for (int i = tid; i < FIN_BUCKETS; i += FIN_THREADS) s_head[i] = -1;
     __syncthreads();
+    // bitonic sort, one compare-exchange per thread and stage: thread t owns the pair (i, i | j) with bit j of i clear
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += FIN_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = s_key[i], c = s_key[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { s_key[i] = c; s_key[ixj] = a; }
-                }
+            for (int t = tid; t < (np2 >> 1); t += FIN_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+                const unsigned long long a = s_key[i], c = s_key[ixj];
+                const bool up = (i & k) == 0;
+                if ((a > c) == up) { s_key[i] = c; s_key[ixj] = a; }
             }
             __syncthreads();
         }
@@ -542,6 +549,15 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
     static_assert(sizeof(short) * VCAP >= ECAP, "status bytes alias s_kx");
     for (int i = tid; i < n; i += FIN_THREADS) s_st[i] = 0;
     if (tid < 3) s_flag[tid] = 0;
+    // cells of ceil(min_dist) pixels: a neighbour within min_dist lies in the 3 x 3 cells around the candidate's
+    const int cs = imax(1, (int)ceilf(min_dist));
+    if (HASH) {
+        for (int i = tid; i < n; i += FIN_THREADS) {
+            const unsigned long long key = s_key[i];
+            const int cx = (int)((key >> 16) & 0xffffu) / cs, cy = (int)(key & 0xffffu) / cs;
+            s_next[i] = (unsigned short)atomicExch(&s_head[(cy * 131 + cx) & (FIN_BUCKETS - 1)], i);     // -1 -> 0xffff ends a chain
+        }
+    }
     __syncthreads();
     const float md2 = min_dist * min_dist;
     for (int round = 0; round < n; round++) {
@@ -551,14 +567,23 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
             const unsigned long long key = s_key[i];
             const int x = (int)((key >> 16) & 0xffffu), y = (int)(key & 0xffffu);
             int verdict = 1;                                             // kept unless an earlier neighbour objects
-            for (int j = 0; j < i; j++) {
+            auto look = [&](int j) {
                 const unsigned long long kj = s_key[j];
                 const float ddx = (float)(x - (int)((kj >> 16) & 0xffffu)), ddy = (float)(y - (int)(kj & 0xffffu));
                 if (ddx * ddx + ddy * ddy < md2) {
                     const int sj = s_st[j];
-                    if (sj == 1) { verdict = 2; break; }
-                    if (sj == 0) verdict = 0;                            // must wait for j
+                    if (sj == 1) verdict = 2;
+                    else if (sj == 0 && verdict == 1) verdict = 0;       // must wait for j
                 }
+            };
+            if (HASH) {
+                const int cx = x / cs, cy = y / cs;
+                for (int oy = -1; oy <= 1 && verdict != 2; oy++)
+                    for (int ox = -1; ox <= 1 && verdict != 2; ox++)
+                        for (int j = s_head[((cy + oy) * 131 + cx + ox) & (FIN_BUCKETS - 1)]; j != -1 && j != 0xffff && verdict != 2; j = s_next[j])
+                            if (j < i) look(j);
+            } else {
+                for (int j = 0; j < i && verdict != 2; j++) look(j);
             }
             if (verdict) s_st[i] = (unsigned char)verdict; else undecided_left = true;
         }
@@ -569,20 +594,18 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
         __syncthreads();
         if (s_flag[round % 3] == 0) break;
     }
-    // ordered compaction of the kept circles (block-wide inclusive scan over chunks of FIN_THREADS candidates)
+    // ordered compaction of the kept circles: positions from the wave's ballot, wave totals summed through LDS
     int base = 0;
+    const int lane = tid & 63, wave = tid >> 6;
     for (int c0 = 0; c0 < n; c0 += FIN_THREADS) {
         const int i = c0 + tid;
         const int keep = (i < n && s_st[i] == 1) ? 1 : 0;
-        s_scan[tid] = keep;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wsum[wave] = __popcll(m);
         __syncthreads();
-        for (int d = 1; d < FIN_THREADS; d <<= 1) {
-            const int v = tid >= d ? s_scan[tid - d] : 0;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        const int pos = base + s_scan[tid] - keep;
+        int before = 0, total = 0;
+        for (int q = 0; q < FIN_THREADS / 64; q++) { const int c = s_wsum[q]; total += c; if (q < wave) before += c; }
+        const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
         if (keep && pos < g.vcirc_cap) {
             const unsigned long long key = s_key[i];
             const int x = (int)((key >> 16) & 0xffffu), y = (int)(key & 0xffffu);
@@ -592,7 +615,7 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
             o[1] = ((float)y + 0.5f) * 1.0f;
             o[2] = (float)sr / 2.f / 10.f * 1.0f + (float)min_r;
         }
-        base += s_scan[FIN_THREADS - 1];
+        base += total;
         __syncthreads();
     }
     if (tid == 0) {
