@@ -218,6 +218,11 @@ def test_jpeg_decode_matches_pillow(lib):
     buf = io.BytesIO()
     Image.fromarray(base[:99, :131]).save(buf, "JPEG", quality=75)
     blobs.append(buf.getvalue())
+    # the same coefficients as one scan per component (tests/jpeg_transcode.py): a sequential file Pillow reads but cannot write
+    import jpeg_transcode
+    buf = io.BytesIO()
+    Image.fromarray(col[:61, :83]).save(buf, "JPEG", quality=70, subsampling=2)
+    blobs.append(jpeg_transcode.to_non_interleaved(buf.getvalue(), [1, 2, 0]))
     refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
     det = Detector(0, len(blobs), 300, 260, lib=lib)
     dets = det.detect_jpeg(blobs, Params(jpeg_entropy_device=2), full=True)

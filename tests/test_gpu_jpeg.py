@@ -269,3 +269,25 @@ def test_fill_bytes_and_iteration_limit(on_device):
         np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d, one round allowed" % k)
     assert det.jpeg_last_rounds() == 0
     det.close()
+
+
+def test_non_interleaved_sequential_scans(on_device):
+    """One scan per component in a sequential file (legal, rare; Pillow cannot write it: tests/jpeg_transcode.py rewrites Pillow's
+    interleaved scan).  The MCU of such a scan is one block and only blocks that hold samples are coded, so the chroma scans of
+    a subsampled image cover fewer blocks than their coefficient arrays have."""
+    import jpeg_transcode
+    rng = np.random.default_rng(808)
+    files = []
+    for sub, (h, w) in ((0, (53, 75)), (1, (97, 131)), (2, (120, 203)), (2, (8, 8)), (1, (33, 17))):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([(xx * 3 + yy) % 256, (yy * 5) % 256, (xx + yy * 2) % 256], -1).astype(np.uint8)
+        img[h // 4:h // 2, w // 4:w // 2] = rng.integers(0, 256, (h // 2 - h // 4, w // 2 - w // 4, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=int(rng.integers(40, 95)), subsampling=sub)
+        files.append(jpeg_transcode.to_non_interleaved(buf.getvalue(), [2, 0, 1] if sub == 1 else None))
+    refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in files]
+    det = Detector(0, len(files), 256, 256)
+    det.detect_jpeg(files, Params(jpeg_entropy_device=on_device), full=False)
+    for k, r in enumerate(refs):
+        np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d" % k)
+    det.close()
