@@ -147,20 +147,25 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
                                             unsigned vx_n, unsigned vy_n, int offx, int offy, int min_r, int nsteps,
                                             unsigned* __restrict__ s_acc)
 {
+    // x, y: 22.10 fixed point relative to the LDS tile's first cell (the valid-cell origin (vx_lo, vy_lo) sits at (offx, offy) in
+    // the tile), so that one unsigned compare per axis against the limits below is the whole range test and the shifted
+    // coordinates index the tile directly.  In a tile on the image's left / top border this also lets through the cells of
+    // column / row -1: they land in the apron, which there is only ever read as the neighbour of a column-0 / row-0 cell, and
+    // those are never centre candidates (OpenCV scans rows / columns 1 ..).
     int sx = 0, sy = 0, x = -1024, y = -1024;          // idle lanes sit at cell (-1, -1): never in range
     if (lane < count) {
         const unsigned item = ring[lane];
         const uint2 e = bin_ent[item & 0x7fffffffu];   // read a moment ago by the culling pass: an L1 / L2 hit
         sx = (int)(short)(e.y & 0xffffu); sy = (int)(short)(e.y >> 16);
         if (item >> 31) { sx = -sx; sy = -sy; }
-        x = (((int)(e.x & 0xffffu) - vx_lo) << 10) + min_r * sx;
-        y = (((int)(e.x >> 16) - vy_lo) << 10) + min_r * sy;
+        x = (((int)(e.x & 0xffffu) - vx_lo + offx) << 10) + min_r * sx;
+        y = (((int)(e.x >> 16) - vy_lo + offy) << 10) + min_r * sy;
     }
+    const unsigned xl = (vx_n + (unsigned)offx) << 10, yl = (vy_n + (unsigned)offy) << 10;
     auto step = [&]() {
-        const unsigned tx = (unsigned)(x >> 10), ty = (unsigned)(y >> 10);
-        if (tx < vx_n && ty < vy_n) {
-            const unsigned cy = ty + (unsigned)offy;
-            atomicAdd(&s_acc[(cy & 63u) * (unsigned)VASTR + tx + (unsigned)offx], (cy & 64u) ? 0x10000u : 1u);
+        if ((unsigned)x < xl && (unsigned)y < yl) {
+            const unsigned ty = (unsigned)y >> 10;
+            atomicAdd(&s_acc[(ty & 63u) * (unsigned)VASTR + ((unsigned)x >> 10)], (unsigned)y >= (64u << 10) ? 0x10000u : 1u);
         }
         x += sx; y += sy;
     };
