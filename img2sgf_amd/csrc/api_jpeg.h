@@ -46,9 +46,9 @@ static void rc_parallel_for(int n, F&& fn)
 // ---- entropy decoding of one pass of JPEG files ---------------------------------------------------------------------------
 // The coefficient arrays of the pass (ctx->h_jd[i].coef[c], laid out by the caller inside ctx->d_jpg, ncoef bytes in all) are
 // zeroed and filled, three ways:
-//   jpeg_parallel : sequential files, parallel inside each scan (k_jpeg_entropy.h)
-//   jpeg_lanes    : any file, one lane per file (k_jpeg_huffman)
-//   jpeg_on_host  : any file, one host thread per file (jpeg_host.h), then one upload per component
+//   jpeg_parallel                       : sequential files, parallel inside each scan (k_jpeg_entropy.h)
+//   jpeg_lanes                          : any file, one lane per file (k_jpeg_huffman)
+//   jpeg_host_decode + jpeg_host_upload : any file, one host thread per file (jpeg_host.h), then one upload per component
 // mode (i2s_params.jpeg_entropy_device): 0 = all on host threads; 1 = sequential files in parallel on the device, the others
 // (progressive, or entropy-coded data with anything but stuffed FF00 and RSTn in it) on host threads; 2 = those on lanes.
 
@@ -100,7 +100,7 @@ static int jpeg_host_upload(i2s_ctx* ctx, const std::vector<int>& list, const st
     return I2S_OK;
 }
 
-// Launches the lane decoder for `list`; the verdicts land in ctx->h_jstatus[i] after the next stream synchronisation.
+// Runs the lane decoder for `list`; the verdicts are in ctx->d_jstatus[i].
 static int jpeg_lanes(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const uint8_t* const* jpeg, const size_t* len,
                       const int* order, std::vector<uint8_t>& bytes)
 {

@@ -83,7 +83,7 @@ __device__ __constant__ const uint8_t JPG_ZZ_DEV[64] = {0,  1,  8,  16, 9,  2,  
 
 static int jpg_build_huff(const uint8_t* counts, const uint8_t* syms, int nsyms, JpegHuff* h)
 {
-    memset(h->look_len, 0, sizeof(h->look_len));
+    memset(static_cast<void*>(h), 0, sizeof(*h));      // padding and the unused entries too: equal tables compare equal byte for byte (the passes pool them)
     memcpy(h->syms, syms, (size_t)nsyms);
     int code = 0, k = 0;
     for (int l = 1; l <= 16; l++) {
@@ -111,6 +111,7 @@ static int jpg_parse(const uint8_t* d, size_t n, JpegFile* f)
     size_t p = 2;
     bool have_frame = false, adobe_rgb = false, latched[3] = {false, false, false};
     JpegHuff dc[4], ac[4];
+    memset(static_cast<void*>(dc), 0, sizeof(dc)); memset(static_cast<void*>(ac), 0, sizeof(ac));
     int dri = 0;
     int cbits[3][10];                 // libjpeg's coef_bits for coefficients 0..9 (zigzag order): -1 = never sent, else the last Al
     for (int c = 0; c < 3; c++) for (int k = 0; k < 10; k++) cbits[c][k] = -1;
