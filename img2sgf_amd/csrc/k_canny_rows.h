@@ -23,11 +23,11 @@ struct CrThr { unsigned lowp, highp, high0p; };
 __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned r1, unsigned c0, unsigned c2, unsigned l0, unsigned r0,
                                             unsigned l2, unsigned r2, unsigned gxp, unsigned gyp, const CrThr& th, unsigned& o, unsigned& om)
 {
-    const unsigned c_h = pk_gt(cur, l1) & ~pk_gt(r1, cur);
-    const unsigned c_v = pk_gt(cur, c0) & ~pk_gt(c2, cur);
-    // diagonal: signs differ -> (above right, below left), else (above left, below right)
+    // The two neighbours of the pixel's sector are selected first and compared once: horizontal (left, right), vertical
+    // (above, below), diagonal by the gradient signs -- signs differ -> (above right, below left), else (above left, below
+    // right).  OpenCV keeps cur > first && cur >= second on the axes and cur > both on a diagonal; cur > d  <=>  cur >= d + 1.
     const unsigned msk = pk_bits(pk_from(gxp ^ gyp) >> 15);
-    const unsigned c_d = pk_gt(cur, bsel(msk, r0, l0)) & pk_gt(cur, bsel(msk, l2, r2));
+    const unsigned d1 = bsel(msk, r0, l0), d2 = pk_bits(pk_from(bsel(msk, l2, r2)) + (short)1);
     const v2u ax = pku_from(pk_bits(pk_abs(pk_from(gxp))));
     const unsigned ay = pk_bits(pk_abs(pk_from(gyp)));
     // |dy| 2^15 < |dx| 13573  <=>  |dy| <= q,  |dy| 2^15 > |dx| 79109  <=>  |dy| > 2 |dx| + q,  q = floor(|dx| 13573 / 2^15) = (|dx| 53 + (|dx| 5 >> 8)) >> 7:
@@ -35,7 +35,8 @@ __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned 
     const v2u q = (ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7;
     const unsigned s22 = ~pk_gt(ay, pku_bits(q));
     const unsigned s67 = pk_gt(ay, pku_bits(ax + ax + q));
-    const unsigned keep = bsel(s22, c_h, bsel(s67, c_v, c_d));
+    const unsigned n1 = bsel(s22, l1, bsel(s67, c0, d1)), n2 = bsel(s22, r1, bsel(s67, c2, d2));
+    const unsigned keep = pk_gt(cur, n1) & ~pk_gt(n2, cur);
     const unsigned kept = keep & pk_gt(cur, th.lowp);
     o = (kept & pk_gt(cur, th.highp) & 0x00020002u) | (~kept & 0x00010001u);
     om = (kept & pk_gt(cur, th.high0p) & 0x00020002u) | (~kept & 0x00010001u);
