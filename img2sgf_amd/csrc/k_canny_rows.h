@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     uint8_t* mp = maps + ((size_t)m_first * g.nb + b) * g.slot;
     uint8_t* mp0 = (main_mode == 2 && main_out) ? maps + (size_t)b * g.slot : nullptr;
     uint8_t* ep = main_out ? edges + (size_t)b * g.slot : nullptr;
+    const BlBuf pbuf = bl_buf(plane), mbuf = bl_buf(mp), m0buf = bl_buf(mp0 ? mp0 : mp), ebuf = bl_buf(ep ? ep : mp);
     CrThr th;
     th.lowp = (unsigned)(iclamp(low, -1, 4095) & 0xffff) * 0x00010001u;
     th.highp = (unsigned)(iclamp(high, -1, 4095) & 0xffff) * 0x00010001u;
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
 
     unsigned nM, nE;
     {
-        const uint8_t* rp = plane + rowoff(iclamp(y0 - 2, 0, h - 1), sp);
-        nM = bl_load(rp, xm);
-        nE = bl_load(rp, xeo);
+        const int ro = rowoff(iclamp(y0 - 2, 0, h - 1), sp);
+        nM = bl_bload(pbuf, ro, xm);
+        nE = bl_bload(pbuf, ro, xeo);
     }
     unsigned wk_acc = 0, wk0_acc = 0;
     static_assert((CR_R + 4) % 6 == 0, "the row loop is unrolled by the ring depths (3 and 2)");
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
             const int yi = y0 - 2 + t;                                 // input row (clamped when outside)
             const unsigned M = nM, E = nE;
             {
-                const uint8_t* rp = plane + rowoff(iclamp(yi + 1, 0, h - 1), sp);
-                nM = bl_load(rp, xm);
-                nE = bl_load(rp, xeo);
+                const int ro = rowoff(iclamp(yi + 1, 0, h - 1), sp);
+                nM = bl_bload(pbuf, ro, xm);
+                nE = bl_bload(pbuf, ro, xeo);
             }
             unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E), Mf = M;
             if (fix) {
@@ -214,9 +215,9 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
             BL_SCHED_FENCE();
             if (emit && active) {
                 const int off = rowoff(yn, g.pitch);
-                bl_store(mp + off, xm, outw);
-                if (mp0) bl_store(mp0 + off, xm, outw0);
-                if (ep) { const unsigned outm = mp0 ? outw0 : outw; bl_store(ep + off, xm, ((outm >> 1) & 0x01010101u) * 0xffu); }
+                bl_bstore(mbuf, off, xm, outw);
+                if (mp0) bl_bstore(m0buf, off, xm, outw0);
+                if (ep) { const unsigned outm = mp0 ? outw0 : outw; bl_bstore(ebuf, off, xm, ((outm >> 1) & 0x01010101u) * 0xffu); }
             }
             // hysteresis worklist: at the last row of a row of 64 x 32 tiles, one key per tile (16 lanes) that holds a weak pixel
             if (emit && ((yn & (CT_H - 1)) == CT_H - 1 || yn == h - 1)) {
