@@ -151,8 +151,11 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
             const int g2 = u % 2;                                      // gradient ring slot
             if (t >= 2) {
                 const int top = (u + 1) % 3, mid = (u + 2) % 3, bot = ps;
-                unsigned dx01 = 0, dx23 = 0, dy01 = 0, dy23 = 0, mg01 = 0, mg23 = 0, mge = 0;
-                if (yg >= 0 && yg < h) {
+                unsigned dx01, dx23, dy01, dy23, mg01, mg23, mge;
+                // gradient rows outside the image (yg = -1, h) are zero: folded into the column masks (a branch around the block
+                // costs seven register clears on every row for the sake of two rows per image)
+                const unsigned rowm = (yg >= 0 && yg < h) ? 0xffffffffu : 0u;
+                {
                     const v2s ta = pk_from(PA[top]), tb = pk_from(PB[top]), tc = pk_from(PC[top]);
                     const v2s ma = pk_from(PA[mid]), mb = pk_from(PB[mid]), mc = pk_from(PC[mid]);
                     const v2s ba = pk_from(PA[bot]), bb = pk_from(PB[bot]), bc = pk_from(PC[bot]);
@@ -162,8 +165,9 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                     const v2s m01 = pk_from(__builtin_amdgcn_alignbit(pk_bits(db), pk_bits(da), 16));    // (dif0, dif1)
                     const v2s m23 = pk_from(__builtin_amdgcn_alignbit(pk_bits(dc), pk_bits(db), 16));    // (dif2, dif3)
                     const v2s y01 = da + m01 + m01 + db, y23 = db + m23 + m23 + dc;
-                    dx01 = pk_bits(x01) & k01; dy01 = pk_bits(y01) & k01;
-                    dx23 = pk_bits(x23) & k23; dy23 = pk_bits(y23) & k23;
+                    const unsigned r01 = k01 & rowm, r23 = k23 & rowm;
+                    dx01 = pk_bits(x01) & r01; dy01 = pk_bits(y01) & r01;
+                    dx23 = pk_bits(x23) & r23; dy23 = pk_bits(y23) & r23;
                     mg01 = pk_bits(pk_abs(pk_from(dx01)) + pk_abs(pk_from(dy01)));
                     mg23 = pk_bits(pk_abs(pk_from(dx23)) + pk_abs(pk_from(dy23)));
                     // end lanes: magnitude at column xe from bytes (xe - 1, xe, xe + 1) of the three rows
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                     const int sc = (int)__builtin_amdgcn_udot4(et, 0x00010000u, __builtin_amdgcn_udot4(em, 0x00020000u, __builtin_amdgcn_udot4(eb, 0x00010000u, 0u, false), false), false);
                     const int sa = (int)__builtin_amdgcn_udot4(et, 0x00000001u, __builtin_amdgcn_udot4(em, 0x00000002u, __builtin_amdgcn_udot4(eb, 0x00000001u, 0u, false), false), false);
                     const int edy = (int)__builtin_amdgcn_udot4(eb, 0x00010201u, 0u, false) - (int)__builtin_amdgcn_udot4(et, 0x00010201u, 0u, false);
-                    mge = e_ok ? (unsigned)(iabs_(sc - sa) + iabs_(edy)) : 0u;
+                    mge = e_ok ? (unsigned)(iabs_(sc - sa) + iabs_(edy)) & rowm : 0u;
                 }
                 GX01[g2] = dx01; GX23[g2] = dx23; GY01[g2] = dy01; GY23[g2] = dy23;
                 M01[gs] = mg01; M23[gs] = mg23;
