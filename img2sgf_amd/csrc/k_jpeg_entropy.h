@@ -14,7 +14,7 @@
 //   * k_je_sync, round r: thread i decodes subsequence i from E[i] up to the first boundary at or beyond its end -- X_i(E[i]) --
 //     and stores that as E[i+1] if it differs, which schedules thread i+1 for round r+1.  When a round changes nothing,
 //     E[i+1] = X_i(E[i]) holds for every i and E[0] is exact, so every E[i] is exact by induction: the result does NOT
-//     depend on the streams resynchronising, only the number of rounds does (3-4 on photographs, 7-9 on rendered diagrams: a
+//     depend on the streams resynchronising, only the number of rounds does (7-9 on rendered diagrams, 15-17 on the reference's scans: a
 //     run of identical blocks can hold a false parse in step with the true one and costs one round per subsequence of the run);
 //   * each run also counts the blocks it completed and sums the DC differences per component; k_je_scan turns them into the
 //     block ordinal and the DC predictors at the start of every subsequence (one wave per segment, running sums);
