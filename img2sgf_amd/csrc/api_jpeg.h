@@ -278,6 +278,7 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     I2S_HIP(hipMemcpyAsync(D + o_bs, blk_scan.data(), blk_scan.size() * sizeof(int), hipMemcpyHostToDevice, st));
     I2S_HIP(hipMemsetAsync(D + o_flag, 0, ((size_t)ctx->je_max_rounds + 16) * sizeof(uint32_t), st));
     I2S_HIP(hipMemsetAsync(D + o_acc, 0, (size_t)ntot * sizeof(JeAcc), st));
+    I2S_HIP(hipMemsetAsync(D + o_stamp, 0, (size_t)ntot * sizeof(uint32_t), st));           // no subsequence is scheduled for a round >= 1 yet
     const JeScan* d_scans = reinterpret_cast<const JeScan*>(D + o_scan);
     const JeSeg* d_segs = reinterpret_cast<const JeSeg*>(D + o_seg);
     const int* d_bs = reinterpret_cast<const int*>(D + o_bs);

@@ -115,8 +115,8 @@ __device__ __forceinline__ uint32_t je_peek32(const uint32_t* slot, uint32_t pos
 __device__ __forceinline__ int je_symbol(const JpegHuff& h, uint32_t v, int& len)
 {
     const uint32_t look = v >> 23;
-    const int l = h.look_len[look];
-    if (l) { len = l; return h.look_sym[look]; }
+    const int l = h.look_len[look], sm = h.look_sym[look];     // both reads leave together
+    if (l) { len = l; return sm; }
     int code = (int)look, n = 9;
     while (n < 17 && code > h.maxcode[n]) { code = (code << 1) | (int)((v >> (31 - n)) & 1u); n++; }
     len = n;
@@ -208,6 +208,9 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_sync(const JeScan* __restrict__
     const JeScan& sc = scans[blk_scan[blockIdx.x]];
     const uint32_t g = blockIdx.x * JE_BLOCK + threadIdx.x;
     bool active = g - sc.sub0 < sc.nsub;
+    // after round 0 the stamp alone says who runs (the host zeroes the stamps, and nobody ever stamps the first subsequence
+    // of a segment, whose entry state is exact from the start): no segment look-up for the others
+    if (round > 0 && active && stamp[g] != round) active = false;
     uint32_t j = 0, off_dw = 0, L = 0;
     bool first = true, last = true;
     if (active) {
@@ -217,7 +220,6 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_sync(const JeScan* __restrict__
         L = sg.nbytes * 8;
         last = (j + 1) * JE_SUB_BITS >= L;
         off_dw = sg.off / 4 + j * (JE_SUB_BYTES / 4);
-        if (round > 0 && (first || stamp[g] != round)) active = false;
     }
     if (threadIdx.x == 0) sh.any = 0;
     __syncthreads();
