@@ -6,11 +6,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libi2s_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-I", os.path.join(CSRC, "isa")]
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
+    return sorted(os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs)
 
 
 def needs_build():

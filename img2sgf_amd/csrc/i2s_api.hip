@@ -78,6 +78,7 @@ struct i2s_ctx {
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
     int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
     int* d_chg = nullptr;        // [NMAP][nb][tiles] last hysteresis pass (+1) that changed the tile
+    int* d_mflags = nullptr;     // [nb][bands_y][bands_x] k_median57_bin: the band holds a pixel other than 0 / 255
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
     int* d_lacc = nullptr;
@@ -100,7 +101,7 @@ struct i2s_ctx {
 
 // segments of i2s_last_kernel_timing, in launch order
 static const char* const kSegName[I2S_NSEG] = {
-    "k_grey", "k_blur", "k_median57", "(unused)", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
+    "k_grey", "k_blur", "k_median57_bin", "k_median57", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
     "k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
     "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
 #define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
@@ -164,7 +165,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -207,6 +208,7 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(unsigned short)));
     I2S_HIP(hipMalloc(&ctx->d_weak, 2 * (nb * NMAP * g.tiles + 1) * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_chg, nb * NMAP * g.tiles * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_mflags, nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
     ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
     I2S_HIP(hipMalloc(&ctx->d_src, nb * ctx->src_slot + 256));
@@ -397,7 +399,9 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     bool need_grey = false;
     for (int i = 0; i < nb; i++) {
         ImgDesc& d = ctx->h_desc[i];
-        const bool alias = d.cn == 1 && ((uintptr_t)d.src & 3u) == 0 && (d.sstride & 3) == 0;
+        // (width a multiple of 4 as well: the row kernels fetch whole dwords, which must not reach past the last pixel of a
+        // buffer the library does not own)
+        const bool alias = d.cn == 1 && ((uintptr_t)d.src & 3u) == 0 && (d.sstride & 3) == 0 && (d.w & 3) == 0;
         d.grey = alias ? d.src : plane_ptr(ctx, I2S_PLANE_GREY) + (size_t)i * g.slot;
         d.gpitch = alias ? d.sstride : g.pitch;
         need_grey |= !alias;
@@ -418,6 +422,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemsetAsync(worklist(ctx, 1), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_chg, 0, (size_t)ctx->max_batch * NMAP * g.tiles * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(ctx->d_mflags, 0, (size_t)nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
         uint8_t* map0 = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
         uint8_t* edges = plane_ptr(ctx, I2S_PLANE_EDGES);
@@ -444,9 +449,15 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                                plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
         }
         I2S_SEG(2);
-        hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
-                           plane_ptr(ctx, I2S_PLANE_MEDIAN7), mx, my);
+        {
+            // two-valued bands first (majority votes); the bit-serial kernel then redoes the tiles of bands that are not
+            const int mbx = cdiv(wmax, 1024), mby = cdiv(hmax, MB_R);    // 4 wavefronts x 256 pixels, MB_R rows
+            hipLaunchKernelGGL(k_median57_bin, dim3((unsigned)mbx * mby * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+                               plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mbx, mby);
+        }
         I2S_SEG(3);
+        hipLaunchKernelGGL(k_median57, g_m, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+                           plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mx, my);
         // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
         // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
         const bool fused0 = has_c1 && p->canny_lo == hc_lo;

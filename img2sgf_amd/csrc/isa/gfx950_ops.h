@@ -1,0 +1,67 @@
+// Instruction-level wrappers of the gfx950 kernels: everything that names a machine instruction, a DPP control word, a
+// buffer descriptor or an inline-asm scheduling trick lives here, so that the kernel sources themselves contain no
+// conditional compilation.  The GPU-less test build (tests/emu) puts its own header of the same name -- plain C stand-ins
+// with the same semantics -- in front of this one on the include path; the product build never sees that file.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace i2s {
+
+// three-operand min / med / max: one instruction each (the compiler forms v_med3 but leaves min3 / max3 as two instructions)
+__device__ __forceinline__ int imin3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int imed3(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Two things the compiler must not "improve" (both measured, profiles/r02_a_valu_rate_*.txt):
+//  * a multiply-add whose tap sits in a scalar register issues at HALF rate (v_fmac_f32 with an SGPR operand 4.4 cycles,
+//    with vector operands 2.9), and uniform kernel arguments land in SGPRs -- the taps are moved to vector registers once;
+//  * (float)a + (float)b of two bytes becomes an SDWA integer add + v_cvt_f32_u32 (two half-rate instructions per sum);
+//    converting every byte once with v_cvt_f32_ubyteN and adding floats (full rate) is cheaper.
+__device__ __forceinline__ float bl_vgpr(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v)
+{
+    float r;
+    if (BYTE == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
+    else if (BYTE == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
+    else if (BYTE == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// Neighbour lanes' dwords: DPP whole-wave shifts (one VALU move each) instead of a round trip through the LDS crossbar.
+// The lane without a source keeps the `old` operand (bound_ctrl off), i.e. `fill`, at no extra cost.
+__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v, unsigned fill) { return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v, unsigned fill) { return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+
+// Loads and stores go through a buffer descriptor: plane base in four scalar registers, the row's byte offset in a scalar register, the
+// lane's column offset in one vector register -- `buffer_load_dword v, v_off, s[rsrc], s_row offen` needs no address
+// arithmetic on the vector unit at all, where a global load costs a 64-bit vector add (v_lshl_add_u64) per access
+// (k_sobel_nms_rows 9.06 -> 8.84 us per diagram).
+struct BlBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ BlBuf bl_buf(const void* p)
+{
+    return BlBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)};     // raw, no stride, 2 GB window
+}
+__device__ __forceinline__ unsigned bl_bload(BlBuf b, int row_off, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, row_off, 0); }
+__device__ __forceinline__ void bl_bstore(BlBuf b, int row_off, unsigned off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.r, (int)off, row_off, 0); }
+
+// "The prefetched registers are needed HERE": an empty statement that consumes them, so that the wait for the loads is placed
+// at this point.  On gfx9 loads and stores retire in order through one counter and the compiler, after the branches around
+// the predicated stores, must assume none of them is pending: a wait for last row's load placed AFTER this row's stores
+// therefore drains the stores as well (measured: 41 % of all wave cycles in s_waitcnt).  Waiting for the prefetch first and
+// storing afterwards leaves the stores a whole row of arithmetic to complete.
+#define BL_CONSUME(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define BL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// a value the optimiser cannot see through (keeps sign-mask arithmetic from being folded back into compare + select)
+__device__ __forceinline__ int opaque_vgpr(int d) { asm("" : "+v"(d)); return d; }
+
+// v_alignbyte_b32: bytes n .. n + 3 of the 8-byte value {hi:lo}
+__device__ __forceinline__ unsigned alignbyte(unsigned hi, unsigned lo, unsigned n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
+
+// 0xff / 0x00 per byte from the byte's top bit: v_perm_b32 selectors 8 .. 11 replicate the sign of bytes 1, 3, 5, 7 of {hi:lo};
+// with hi = t << 8 those are bytes 1, 3 (lo) and 0, 2 (hi) of t.
+__device__ __forceinline__ unsigned bytes_from_sign(unsigned t) { return __builtin_amdgcn_perm(t << 8, t, 0x090b080au); }
+
+}  // namespace i2s

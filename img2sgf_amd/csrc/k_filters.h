@@ -6,6 +6,7 @@
 #pragma once
 #include "i2s_types.h"
 #include "tile_io.h"
+#include <gfx950_ops.h>
 
 namespace i2s {
 
@@ -145,78 +146,12 @@ __global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ de
 // Top / bottom: the Gaussians read row reflect101(y); the median ring repeats the first / last image row.
 // Host side: used when every tap set sums to 256 (always for OpenCV's bit-exact kernels; the plain-rounding compatibility
 // mode can give 257, for which the integer kernels below remain).
-// three-operand min / med / max: one instruction each (the compiler forms v_med3 but leaves min3 / max3 as two instructions)
-#ifdef HIPEMU
-__device__ __forceinline__ int imin3(int a, int b, int c) { return imin(imin(a, b), c); }
-__device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
-__device__ __forceinline__ int imed3(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }
-#else
-__device__ __forceinline__ int imin3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ int imax3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ int imed3(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-#endif
 constexpr int BL_R = 64;          // output rows per wavefront (+6 apron rows of horizontal work)
 struct BlurTaps { float c3, a3, c5, a5, b5, c7, a7, b7, d7; };   // centre, +-1, +-2, +-3 of the 3 / 5 / 7-tap kernels
-
-// Two things the compiler must not "improve" (both measured, profiles/r02_a_valu_rate_*.txt):
-//  * a multiply-add whose tap sits in a scalar register issues at HALF rate (v_fmac_f32 with an SGPR operand 4.4 cycles,
-//    with vector operands 2.9), and uniform kernel arguments land in SGPRs -- the taps are moved to vector registers once;
-//  * (float)a + (float)b of two bytes becomes an SDWA integer add + v_cvt_f32_u32 (two half-rate instructions per sum);
-//    converting every byte once with v_cvt_f32_ubyteN and adding floats (full rate) is cheaper.
-// The emulated build (tests/emu, HIPEMU) has no instruction set: there the plain C expressions stand in.
-#ifdef HIPEMU
-__device__ __forceinline__ float bl_vgpr(float x) { return x; }
-template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v) { return (float)((v >> (8 * BYTE)) & 0xffu); }
-#else
-__device__ __forceinline__ float bl_vgpr(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
-template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v)
-{
-    float r;
-    if (BYTE == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
-    else if (BYTE == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
-    else if (BYTE == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v));
-    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-#endif
 #define bl_f(v, byte) bl_fb<byte>(v)
-// Neighbour lanes' dwords: DPP whole-wave shifts (one VALU move each) instead of a round trip through the LDS crossbar.
-#ifdef HIPEMU
-// value of lane - 1 / lane + 1; lane 0 / lane 63, which have no such neighbour, get `fill`
-__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v, unsigned fill) { const unsigned u = (unsigned)__shfl_up((int)v, 1); return __lane_id() == 0 ? fill : u; }
-__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v, unsigned fill) { const unsigned u = (unsigned)__shfl_down((int)v, 1); return __lane_id() == 63 ? fill : u; }
-struct BlBuf { uint8_t* p; };
-__device__ __forceinline__ BlBuf bl_buf(const void* p) { return BlBuf{const_cast<uint8_t*>(static_cast<const uint8_t*>(p))}; }
-__device__ __forceinline__ unsigned bl_bload(BlBuf b, int row_off, unsigned off) { return *reinterpret_cast<const unsigned*>(b.p + row_off + off); }
-__device__ __forceinline__ void bl_bstore(BlBuf b, int row_off, unsigned off, unsigned v) { *reinterpret_cast<unsigned*>(b.p + row_off + off) = v; }
-#else
-// DPP whole-wave shifts; the lane without a source keeps the `old` operand (bound_ctrl off), i.e. `fill`, at no extra cost
-__device__ __forceinline__ unsigned bl_from_prev_lane(unsigned v, unsigned fill) { return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
-__device__ __forceinline__ unsigned bl_from_next_lane(unsigned v, unsigned fill) { return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
-// Loads and stores go through a buffer descriptor: plane base in four scalar registers, the row's byte offset in a scalar register, the
-// lane's column offset in one vector register -- `buffer_load_dword v, v_off, s[rsrc], s_row offen` needs no address
-// arithmetic on the vector unit at all, where a global load costs a 64-bit vector add (v_lshl_add_u64) per access
-// (k_sobel_nms_rows 9.06 -> 8.84 us per diagram).
-struct BlBuf { __amdgpu_buffer_rsrc_t r; };
-__device__ __forceinline__ BlBuf bl_buf(const void* p)
-{
-    return BlBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000)};     // raw, no stride, 2 GB window
-}
-__device__ __forceinline__ unsigned bl_bload(BlBuf b, int row_off, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, row_off, 0); }
-__device__ __forceinline__ void bl_bstore(BlBuf b, int row_off, unsigned off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.r, (int)off, row_off, 0); }
-#endif
-// "The prefetched registers are needed HERE": an empty statement that consumes them, so that the wait for the loads is placed
-// at this point.  On gfx9 loads and stores retire in order through one counter and the compiler, after the branches around
-// the predicated stores, must assume none of them is pending: a wait for last row's load placed AFTER this row's stores
-// therefore drains the stores as well (measured: 41 % of all wave cycles in s_waitcnt).  Waiting for the prefetch first and
-// storing afterwards leaves the stores a whole row of arithmetic to complete.
-#ifdef HIPEMU
-#define BL_CONSUME(a, b) do { } while (0)
-#define BL_SCHED_FENCE() do { } while (0)
-#else
-#define BL_CONSUME(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#define BL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
+// Machine-level pieces (isa/gfx950_ops.h): imin3 / imed3 / imax3, bl_vgpr + bl_fb (taps in vector registers, bytes converted
+// with v_cvt_f32_ubyteN), bl_from_prev_lane / bl_from_next_lane (DPP whole-wave shifts), BlBuf loads / stores through a buffer
+// descriptor, BL_CONSUME / BL_SCHED_FENCE (the wait for the prefetched row is placed BEFORE the row's stores).
 // BORDER_REFLECT_101 of a row index that moves by one per step: (row, direction) instead of a modulo per row
 struct BlReflect {
     int y, dir, n;
@@ -498,6 +433,127 @@ __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ des
 // neither kept in the ring nor given a round.  Line art -- a diagram of pure black and white, a scan after the reference's
 // contrast step -- has ONE distinct plane and costs a round instead of eight; a noisy photograph has eight and costs what
 // it did (DESIGN.md quotes both).
+// ---- K4, two-valued bands: 5x5 and 7x7 medians of 0 / 255 pixels are majority votes ------------------------------------------
+// A diagram of pure black and white (the benchmark's; a scan after the reference's contrast step mostly) needs no median
+// machinery at all: with every pixel of the window 0 or 255, the 5x5 median is 255 iff at least 13 of the 25 are, the 7x7
+// median iff at least 25 of the 49 -- a box sum and a compare, separable.  k_median57_bin runs first, register-resident in the
+// manner of k_blur: a lane owns one dword column (4 pixels), a wavefront 256 pixels of a row, and walks down MB_R output
+// rows; per input row the pixels become 0 / 1 bytes, the horizontal 5- and 7-sums are byte-shifted adds of the (left, mid,
+// right) dword triple (no carries: a byte never exceeds 49), rings of the last 7 rows keep the vertical running sums, and
+// sum + (128 - need) has its top bit set exactly when the majority is 255 (v_perm's sign selectors turn that bit into the byte).
+// SPECULATIVE and exact: every dword the band reads (3 rows above and below, one dword left and right) is also tested for a
+// byte that is neither 0 nor 255; at the first such byte the wavefront raises its band's flag and leaves.  k_median57 (the
+// general bit-serial kernel, below) then runs on every tile that touches a flagged band and overwrites whatever the band
+// wrote; tiles whose bands all stayed silent return at once.  Either way every output pixel is an exact median.
+constexpr int MB_R = 64;          // output rows per wavefront (+6 apron rows); a band = 256 x MB_R pixels
+__device__ __host__ inline int mb_bands_x(int wmax) { return (wmax + 255) / 256; }
+__device__ __host__ inline int mb_bands_y(int hmax) { return (hmax + MB_R - 1) / MB_R; }
+
+// flags[(b * bands_y + band row) * bands_x + column group] != 0: the band holds a pixel other than 0 / 255 (zeroed by the host)
+__global__ __launch_bounds__(256) void k_median57_bin(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ out5,
+                                                      uint8_t* __restrict__ out7, int* __restrict__ flags, int gx, int gy)
+{
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z;
+    const ImgDesc im = desc[b];
+    const int w = im.w, h = im.h;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cgp = tl.tx * 4 + wave;                                // 256-pixel column group
+    const int x0 = (cgp * 64 + lane) * 4;
+    const int y0 = tl.ty * MB_R;
+    if (cgp * 256 >= w || y0 >= h) return;                            // whole wavefront outside the image
+    int* flag = flags + ((size_t)b * mb_bands_y(g.hmax) + tl.ty) * mb_bands_x(g.wmax) + cgp;
+    const bool active = x0 < w;
+    const size_t obase = (size_t)b * g.slot;
+    // BORDER_REPLICATE along x: byte k of the (L, M, R) triple is pixel x0 - 4 + k; lanes whose 3 x 4 bytes reach outside the
+    // image rebuild the triple with byte permutes (selectors computed once): L' = perm(M, L), M' = perm(M, L), R' = perm(R, M)
+    const bool fix_lane = active && (x0 - 4 < 0 || x0 + 7 >= w);
+    const bool fix = __any(fix_lane ? 1 : 0) != 0;
+    unsigned sL = 0x03020100u, sM = 0x07060504u, sR = 0x07060504u;
+    if (fix_lane) {
+        sL = 0; sM = 0; sR = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sL |= (unsigned)iclamp(iclamp(x0 - 4 + j, 0, w - 1) - (x0 - 4), 0, 7) << (8 * j);
+            sM |= (unsigned)iclamp(iclamp(x0 + j, 0, w - 1) - (x0 - 4), 0, 7) << (8 * j);
+            sR |= (unsigned)iclamp(iclamp(x0 + 4 + j, 0, w - 1) - x0, 0, 7) << (8 * j);
+        }
+    }
+    // bytes of the lane's dwords that are pixels of the image (only those are tested for "neither 0 nor 255")
+    unsigned vm = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (x0 + q < w) vm |= 0x7fu << (8 * q);
+    const bool has_e = (lane == 0 && x0 >= 4) || (lane == 63 && x0 + 4 < w);
+    unsigned ve = 0;
+    if (has_e) {
+        const int xe0 = lane == 0 ? x0 - 4 : x0 + 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (xe0 + q < w) ve |= 0x7fu << (8 * q);
+    }
+    const unsigned xm = active ? (unsigned)x0 : 0u, xe = has_e ? (unsigned)(lane == 0 ? x0 - 4 : x0 + 4) : 0u;
+    if (!active) vm = 0;
+
+    unsigned H5[7], H7[7];                      // horizontal sums of the last 7 input rows, slot = row index mod 7
+#pragma unroll
+    for (int i = 0; i < 7; i++) { H5[i] = 0; H7[i] = 0; }
+    unsigned S5 = 0, S7 = 0;                    // vertical running sums
+    const BlBuf sbuf = bl_buf(im.grey);
+    const int sp = im.gpitch;
+    unsigned nM, nE;
+    {
+        const int ro = rowoff(iclamp(y0 - 3, 0, h - 1), sp);
+        nM = bl_bload(sbuf, ro, xm);
+        nE = bl_bload(sbuf, ro, xe);
+    }
+    static_assert((MB_R + 6) % 7 == 0, "the row loop is unrolled by the ring depth");
+    const int t_end = imin(MB_R + 6, h + 3 - (y0 - 3));               // input rows beyond h + 2 feed no output of this band
+    const BlBuf o_5 = bl_buf(out5 + obase), o_7 = bl_buf(out7 + obase);
+    for (int t0 = 0; t0 < t_end; t0 += 7) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int t = t0 + u;
+            const int yi = y0 - 3 + t;                                 // input row (BORDER_REPLICATE: clamped when outside)
+            const unsigned M = nM, E = nE;
+            {
+                const int ro = rowoff(iclamp(yi + 1, 0, h - 1), sp);
+                nM = bl_bload(sbuf, ro, xm);
+                nE = bl_bload(sbuf, ro, xe);
+            }
+            // a byte is 0 or 255 iff each of its bits equals the next higher one
+            const unsigned odd = (((M >> 1) ^ M) & vm) | (((E >> 1) ^ E) & ve);
+            if (__any(odd != 0u)) {
+                if (lane == 0) *flag = 1;
+                return;
+            }
+            unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E), Mf = M;
+            if (fix) {
+                const unsigned l2 = __builtin_amdgcn_perm(M, L, sL), m2 = __builtin_amdgcn_perm(M, L, sM), r2 = __builtin_amdgcn_perm(R, M, sR);
+                L = l2; Mf = m2; R = r2;
+            }
+            const unsigned fl = L & 0x01010101u, fm = Mf & 0x01010101u, fr = R & 0x01010101u;
+            // byte q of the sums = pixel x0 + q: pixels x0 + q - 2 .. x0 + q + 2 are bytes q + 2 .. q + 6 of the triple
+            const unsigned h5 = alignbyte(fm, fl, 2) + alignbyte(fm, fl, 3) + fm + alignbyte(fr, fm, 1) + alignbyte(fr, fm, 2);
+            const unsigned h7 = h5 + alignbyte(fm, fl, 1) + alignbyte(fr, fm, 3);
+            // output row yo = yi - 3: 7x7 = input rows t - 6 .. t, 5x5 = rows t - 5 .. t - 1
+            S7 += h7 - H7[u];
+            S5 += H5[(u + 6) % 7] - H5[(u + 1) % 7];
+            H7[u] = h7; H5[u] = h5;
+            const int yo = yi - 3;
+            const bool st = t >= 6 && yo < h;
+            const unsigned o5 = bytes_from_sign(S5 + 0x73737373u);    // + (128 - 13): top bit <=> at least 13 of 25
+            const unsigned o7 = bytes_from_sign(S7 + 0x67676767u);    // + (128 - 25): top bit <=> at least 25 of 49
+            BL_SCHED_FENCE();
+            BL_CONSUME(nM, nE);
+            BL_SCHED_FENCE();
+            if (st && active) {
+                const int off = rowoff(yo, g.pitch);
+                bl_bstore(o_5, off, xm, o5);
+                bl_bstore(o_7, off, xm, o7);
+            }
+        }
+    }
+}
+
 constexpr int MT_W = 56, MT_H = 72, M_RPT = 8;
 constexpr int M_ROWS = MT_H + 6, M_SSTR = 17;
 
@@ -508,9 +564,7 @@ __device__ __forceinline__ void med_round(MedState& s, unsigned plo, unsigned ph
 {
     const int c = __popc(s.alo & plo) + __popc(s.ahi & phi);
     int d = c - s.need;
-#ifndef HIPEMU
-    asm("" : "+v"(d));                                 // opaque: otherwise the compiler turns the sign mask back into compare + selects
-#endif
+    d = opaque_vgpr(d);                                // opaque: otherwise the compiler turns the sign mask back into compare + selects
     const int nm = d >> 31;                            // all ones iff c < need: the median's bit is 0
     s.alo &= plo ^ (unsigned)nm;                       // keep the candidates whose bit equals the median's
     s.ahi &= phi ^ (unsigned)nm;
@@ -524,8 +578,10 @@ __device__ __forceinline__ void med_round(MedState& s, unsigned plo, unsigned ph
 // holds, so the median's bit repeats the previous one and neither the candidates nor `need` change.
 __device__ __forceinline__ void med_repeat(MedState& s) { s.r = s.r + s.r - (unsigned)s.nm; }
 
+// flags (optional): the band flags of k_median57_bin; a tile none of whose bands is flagged has exact medians already.
 __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
-                                                  uint8_t* __restrict__ out5, uint8_t* __restrict__ out7, int gx, int gy)
+                                                  uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
+                                                  const int* __restrict__ flags, int gx, int gy)
 {
     __shared__ unsigned s_src[M_ROWS * M_SSTR];
     __shared__ unsigned long long s_pl[8 * M_ROWS];
@@ -535,6 +591,15 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
     const int w = desc[b].w, h = desc[b].h;
     const int x0 = tl.tx * MT_W, y0 = tl.ty * MT_H;
     if (x0 >= w || y0 >= h) return;
+    if (flags) {
+        // bands (256 x MB_R pixels) this tile's OUTPUT pixels lie in: wave-uniform scalar loads, at most 2 x 3 of them
+        const int bx0 = x0 / 256, bx1 = imin(x0 + MT_W - 1, w - 1) / 256, by0 = y0 / MB_R, by1 = imin(y0 + MT_H - 1, h - 1) / MB_R;
+        const int nbx = mb_bands_x(g.wmax), nby = mb_bands_y(g.hmax);
+        int any = 0;
+        for (int by = by0; by <= by1; by++)
+            for (int bx = bx0; bx <= bx1; bx++) any |= flags[((size_t)b * nby + by) * nbx + bx];
+        if (!any) return;
+    }
     const int tid = threadIdx.x;
     if (tid == 0) s_differs = 0;
     load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, desc[b].grey, desc[b].gpitch, w, h, x0 - 4, y0 - 3, tid);

@@ -1,5 +1,7 @@
-"""Builds tests/emu/libi2s_emu.so: the UNMODIFIED product sources (img2sgf_amd/csrc) compiled with g++ against
-the fiber-based HIP emulation in tests/emu/hip/hip_runtime.h.  Test infrastructure only: lets the GPU-less CI
+"""Builds tests/emu/libi2s_emu.so: the product's kernel and host sources (img2sgf_amd/csrc/*) compiled with g++ against
+the fiber-based HIP emulation in tests/emu/hip/hip_runtime.h.  ONE product header is replaced: csrc/isa/gfx950_ops.h (inline
+assembly, DPP, buffer descriptors) by tests/emu/gfx950_ops.h (plain C with the same semantics); those machine-level paths are
+covered by the GPU tests only.  Test infrastructure only: lets the GPU-less CI
 check kernel logic against the oracle.  The product loader never looks at this file."""
 import os
 import subprocess
@@ -11,8 +13,8 @@ LIB = os.path.join(HERE, "libi2s_emu.so")
 
 
 def build(force=False):
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
-        os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not os.path.isdir(os.path.join(CSRC, f))] + [
+        os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "gfx950_ops.h"),
         os.path.join(ROOT, "include", "i2s.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB

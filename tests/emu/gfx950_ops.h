@@ -1,0 +1,27 @@
+// tests/emu/gfx950_ops.h -- TEST INFRASTRUCTURE ONLY.  Plain C stand-ins, with the same semantics, for the instruction-level
+// wrappers of img2sgf_amd/csrc/isa/gfx950_ops.h; the emulated build (tests/emu/build_emu.py) finds this header first.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace i2s {
+
+static inline int imin3(int a, int b, int c) { return std::min(std::min(a, b), c); }
+static inline int imax3(int a, int b, int c) { return std::max(std::max(a, b), c); }
+static inline int imed3(int a, int b, int c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
+static inline float bl_vgpr(float x) { return x; }
+template <int BYTE> static inline float bl_fb(unsigned v) { return (float)((v >> (8 * BYTE)) & 0xffu); }
+// value of lane - 1 / lane + 1; lane 0 / lane 63, which have no such neighbour, get `fill`
+static inline unsigned bl_from_prev_lane(unsigned v, unsigned fill) { const unsigned u = (unsigned)__shfl_up((int)v, 1); return __lane_id() == 0 ? fill : u; }
+static inline unsigned bl_from_next_lane(unsigned v, unsigned fill) { const unsigned u = (unsigned)__shfl_down((int)v, 1); return __lane_id() == 63 ? fill : u; }
+struct BlBuf { uint8_t* p; };
+static inline BlBuf bl_buf(const void* p) { return BlBuf{const_cast<uint8_t*>(static_cast<const uint8_t*>(p))}; }
+static inline unsigned bl_bload(BlBuf b, int row_off, unsigned off) { unsigned v; memcpy(&v, b.p + row_off + off, 4); return v; }
+static inline void bl_bstore(BlBuf b, int row_off, unsigned off, unsigned v) { memcpy(b.p + row_off + off, &v, 4); }
+#define BL_CONSUME(a, b) do { } while (0)
+#define BL_SCHED_FENCE() do { } while (0)
+static inline int opaque_vgpr(int d) { return d; }
+static inline unsigned alignbyte(unsigned hi, unsigned lo, unsigned n) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (n & 3))); }
+static inline unsigned bytes_from_sign(unsigned t) { return ((t >> 7) & 0x01010101u) * 0xffu; }
+
+}  // namespace i2s

@@ -121,7 +121,7 @@ static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long l
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi:lo} (0-3 = lo, 4-7 = hi), 0x0c = 0x00
-static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel)
+static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel)   // 8 .. 11: sign of byte 1, 3, 5, 7 replicated
 {
     const unsigned long long v = ((unsigned long long)hi << 32) | lo;
     unsigned r = 0;
@@ -131,6 +131,7 @@ static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned 
         if (s < 8) b = (unsigned)(v >> (8 * s)) & 0xff;
         else if (s == 0x0c) b = 0;
         else if (s >= 0x0d) b = 0xff;
+        else if (s <= 0x0b) b = ((v >> (8 * (2 * (s - 8) + 1) + 7)) & 1) ? 0xff : 0;
         else { fprintf(stderr, "hipemu: unsupported v_perm selector %#x\n", s); abort(); }
         r |= b << (8 * i);
     }
