@@ -73,6 +73,26 @@ __device__ __forceinline__ TileId tile_of_block(unsigned gx, unsigned gy)
     return id;
 }
 
+// the same for kernels whose workgroups take `per` consecutive tiles each: first tile of this workgroup's chunk (the chunks of
+// one XCD are contiguous), and tile index -> (tx, ty, z)
+__device__ __forceinline__ unsigned tile_chunk_of_block(unsigned per, unsigned ntiles)
+{
+    const unsigned T = gridDim.x, L = blockIdx.x;
+    const unsigned q = T >> 3, r = T & 7u, x = L & 7u, i = L >> 3;
+    (void)ntiles;
+    return ((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i) * per;
+}
+__device__ __forceinline__ TileId tile_of_index(unsigned t, unsigned gx, unsigned gy)
+{
+    const unsigned per = gx * gy;
+    TileId id;
+    id.z = (int)(t / per);
+    const unsigned rem = t - (unsigned)id.z * per;
+    id.ty = (int)(rem / gx);
+    id.tx = (int)(rem - (unsigned)id.ty * gx);
+    return id;
+}
+
 struct HoughTrig {        // tables of the three HoughLines calls of find_lines (img2sgf.py:236-244)
     int n[3];             // number of angles: [0] horizontal, [1] vertical near 0, [2] vertical near pi
     float sin_[3][4];

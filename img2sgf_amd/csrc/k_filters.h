@@ -578,28 +578,11 @@ __device__ __forceinline__ void med_round(MedState& s, unsigned plo, unsigned ph
 // holds, so the median's bit repeats the previous one and neither the candidates nor `need` change.
 __device__ __forceinline__ void med_repeat(MedState& s) { s.r = s.r + s.r - (unsigned)s.nm; }
 
-// flags (optional): the band flags of k_median57_bin; a tile none of whose bands is flagged has exact medians already.
-__global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
-                                                  uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
-                                                  const int* __restrict__ flags, int gx, int gy)
+// One 56 x 72 tile; every thread of the workgroup calls it (it ends with a barrier, so that the LDS arrays may be reused).
+__device__ __forceinline__ void median57_tile(const ImgDesc* __restrict__ desc, const Geo& g, uint8_t* __restrict__ out5,
+                                              uint8_t* __restrict__ out7, int b, int x0, int y0, int w, int h,
+                                              unsigned* __restrict__ s_src, unsigned long long* __restrict__ s_pl, unsigned& s_differs)
 {
-    __shared__ unsigned s_src[M_ROWS * M_SSTR];
-    __shared__ unsigned long long s_pl[8 * M_ROWS];
-    __shared__ unsigned s_differs;                   // bit p: plane p differs from plane p + 1 somewhere in the tile
-    const TileId tl = tile_of_block(gx, gy);
-    const int b = tl.z;
-    const int w = desc[b].w, h = desc[b].h;
-    const int x0 = tl.tx * MT_W, y0 = tl.ty * MT_H;
-    if (x0 >= w || y0 >= h) return;
-    if (flags) {
-        // bands (256 x MB_R pixels) this tile's OUTPUT pixels lie in: wave-uniform scalar loads, at most 2 x 3 of them
-        const int bx0 = x0 / 256, bx1 = imin(x0 + MT_W - 1, w - 1) / 256, by0 = y0 / MB_R, by1 = imin(y0 + MT_H - 1, h - 1) / MB_R;
-        const int nbx = mb_bands_x(g.wmax), nby = mb_bands_y(g.hmax);
-        int any = 0;
-        for (int by = by0; by <= by1; by++)
-            for (int bx = bx0; bx <= bx1; bx++) any |= flags[((size_t)b * nby + by) * nbx + bx];
-        if (!any) return;
-    }
     const int tid = threadIdx.x;
     if (tid == 0) s_differs = 0;
     load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, desc[b].grey, desc[b].gpitch, w, h, x0 - 4, y0 - 3, tid);
@@ -627,10 +610,9 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
     __syncthreads();
     // planes that get a ring and a round: plane 7 and every plane that differs from its upper neighbour (block-uniform)
     const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_differs | 0x80u));
-    if (tid >= 28 * 9) return;
     const int cg = tid % 28, rg = tid / 28;
     const int c = 2 * cg, r0 = rg * M_RPT;           // first tile column / output row of this thread
-    if (x0 + c >= w || y0 + r0 >= h) return;
+    if (tid < 28 * 9 && x0 + c < w && y0 + r0 < h) {
     const int pos = c + 1;                           // plane bit of tile column c - 3
     unsigned rlo[8], rhi[8];                         // window ring per plane: byte k of rlo = row slot k, of rhi = slot 4 + k
 #pragma unroll
@@ -684,6 +666,39 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
                 }
             }
         }
+    }
+    }
+    __syncthreads();
+}
+
+// The general kernel.  flags (optional): the band flags of k_median57_bin; a tile none of whose bands is flagged has exact
+// medians already.  A workgroup looks at M_TPB consecutive tiles of the (plane, row-major tile) sequence: on two-valued
+// diagrams all it does is read their flags (scalar loads), and one workgroup per tile cost more in launches than that.
+constexpr int M_TPB = 8;
+__global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
+                                                  uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
+                                                  const int* __restrict__ flags, int gx, int gy, int ntiles)
+{
+    __shared__ unsigned s_src[M_ROWS * M_SSTR];
+    __shared__ unsigned long long s_pl[8 * M_ROWS];
+    __shared__ unsigned s_differs;                   // bit p: plane p differs from plane p + 1 somewhere in the tile
+    const unsigned first = tile_chunk_of_block(M_TPB, (unsigned)ntiles);
+    for (unsigned k = 0; k < (unsigned)M_TPB && first + k < (unsigned)ntiles; k++) {
+        const TileId tl = tile_of_index(first + k, gx, gy);
+        const int b = tl.z;
+        const int w = desc[b].w, h = desc[b].h;
+        const int x0 = tl.tx * MT_W, y0 = tl.ty * MT_H;
+        if (x0 >= w || y0 >= h) continue;
+        if (flags) {
+            // bands (256 x MB_R pixels) this tile's OUTPUT pixels lie in: wave-uniform scalar loads, at most 2 x 3 of them
+            const int bx0 = x0 / 256, bx1 = imin(x0 + MT_W - 1, w - 1) / 256, by0 = y0 / MB_R, by1 = imin(y0 + MT_H - 1, h - 1) / MB_R;
+            const int nbx = mb_bands_x(g.wmax), nby = mb_bands_y(g.hmax);
+            int any = 0;
+            for (int by = by0; by <= by1; by++)
+                for (int bx = bx0; bx <= bx1; bx++) any |= flags[((size_t)b * nby + by) * nbx + bx];
+            if (!any) continue;
+        }
+        median57_tile(desc, g, out5, out7, b, x0, y0, w, h, s_src, s_pl, s_differs);
     }
 }
 
