@@ -81,8 +81,6 @@ struct i2s_ctx {
     int* d_mflags = nullptr;     // [nb][bands_y][bands_x] k_median57_bin: the band holds a pixel other than 0 / 255
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
-    unsigned* d_hbits = nullptr;    // [nb][NVAR][hmax][pitch / 32]: edge pixels with an exactly horizontal gradient (k_edge_bins)
-    unsigned* d_vbits = nullptr;    // [nb][NVAR][pitch][..]: exactly vertical gradient, column-major
     int* d_lacc = nullptr;
     int lrow = 0;
     i2s_result* d_res = nullptr;
@@ -167,7 +165,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_hbits, ctx->d_vbits, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -231,8 +229,6 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_vcirc, nb * NVAR * g.vcirc_cap * 3 * sizeof(float)));
     I2S_HIP(hipMalloc(&ctx->d_bin_cnt, nb * NVAR * g.bins * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_bin_ent, nb * NVAR * g.bins * EB_CAP * sizeof(uint2)));
-    I2S_HIP(hipMalloc(&ctx->d_hbits, nb * NVAR * g.hmax * ax_hw(g) * sizeof(unsigned) + 256));
-    I2S_HIP(hipMalloc(&ctx->d_vbits, nb * NVAR * g.pitch * ax_vw(g) * sizeof(unsigned) + 256));
     ctx->lrow = (2 * (ctx->max_w + ctx->max_h) + 1 + 15) / 16 * 16;
     I2S_HIP(hipMalloc(&ctx->d_lacc, nb * LROWS * ctx->lrow * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_res, nb * sizeof(i2s_result)));
@@ -487,16 +483,16 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         if (rc) return rc;
         I2S_SEG(8);
         hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
-                           ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_hbits, ctx->d_vbits, ebx, eby);
+                           ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
         I2S_SEG(9);
         // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
         if (p->hc_max_radius - p->hc_min_radius + 1 == 30)
             hipLaunchKernelGGL((k_vote_centres<30>), dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
-                               ctx->d_bin_cnt, ctx->d_hbits, ctx->d_vbits, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                               ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
                                ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
         else
             hipLaunchKernelGGL((k_vote_centres<0>), dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
-                               ctx->d_bin_cnt, ctx->d_hbits, ctx->d_vbits, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                               ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
                                ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
         I2S_SEG(10);
         hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,

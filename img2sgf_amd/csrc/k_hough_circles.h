@@ -42,24 +42,10 @@ __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitc
 // bin of its 32x32-pixel cell.  The vote kernel then streams only the bins within reach of its accumulator tile.
 // grid (ceil(bins_x / EBB_X) * ceil(bins_y / EBB_Y) * nb * NVAR), block 256 (32 pixels per thread).
 // bin_cnt[(bv * g.bins) + by * g.bw + bx], bin_ent[... * EB_CAP + k].
-//
-// Records whose gradient is exactly horizontal (dy == 0, hence (sx, sy) = (+-1024, 0)) or exactly vertical -- the straight
-// grid lines of a diagram, about half of its edge pixels -- are ALSO marked in two bitmaps per (image, variant): their 2 x 30
-// votes are the cells x +- r of their own row (y +- r of their own column), which the vote kernel reads off the bitmaps as
-// window popcounts instead of casting them one LDS atomic at a time.
-//   hbits[(bv * hmax + y) * ax_hw(g) + (x >> 5)]  bit x & 31     (row-major)
-//   vbits[(bv * pitch + x) * ax_vw(g) + (y >> 5)]  bit y & 31     (column-major)
-// Every block that lies in the image writes all of its 64 x 128 bits (zeros included), so the bitmaps need no clearing.
-__device__ __host__ inline int ax_hw(const Geo& g) { return g.pitch / 32; }
-__device__ __host__ inline int ax_vw(const Geo& g) { return (g.hmax + 63) / 64 * 2; }
-
 __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ desc, Geo g,
                                                    const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
-                                                   uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt,
-                                                   unsigned* __restrict__ hbits, unsigned* __restrict__ vbits, int gx, int gy)
+                                                   uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt, int gx, int gy)
 {
-    __shared__ unsigned s_hb[EBB_Y * EB][EBB_X];          // 64 rows x 128 bits
-    __shared__ unsigned s_vb[EBB_X * EB][EBB_Y];          // 128 columns x 64 bits
     // one block = 4 x 2 bins (128 x 64 pixels); two 16-byte map loads per thread, both in flight together (the kernel is
     // latency-bound: load -> compact -> gather -> store).  Edge positions are first compacted into an LDS list (13-bit
     // tile-local coordinates) so that the gradient work (8 neighbour loads, sqrt, 2 divides) is spread evenly over the
@@ -80,8 +66,6 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)tl.ty * EBB_Y * g.bw + (size_t)tl.tx * EBB_X;
     if (tid < EBB_X * EBB_Y) s_n[tid] = 0;
     if (tid == 32) s_nl = 0;
-    (&s_hb[0][0])[tid] = 0;
-    (&s_vb[0][0])[tid] = 0;
     __syncthreads();
     {
         const int ly = tid >> 3, c16 = (tid & 7) * 16;
@@ -140,8 +124,6 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
         if (mag < 1.0f) continue;
         const int sx = __float2int_rn((vx * 1.0f) * 1024.0f / mag);
         const int sy = __float2int_rn((vy * 1.0f) * 1024.0f / mag);
-        if (dy == 0) atomicOr(&s_hb[lyy][lx >> 5], 1u << (lx & 31));
-        if (dx == 0) atomicOr(&s_vb[lx][lyy >> 5], 1u << (lyy & 31));
         const int kbx = lx / EB, kby = lyy / EB;
         const int k = atomicAdd(&s_n[kby * EBB_X + kbx], 1);
         bin_ent[(bin0 + (size_t)kby * g.bw + kbx) * EB_CAP + k] =
@@ -151,13 +133,6 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     if (tid < EBB_X * EBB_Y) {
         const int kbx = tid % EBB_X, kby = tid / EBB_X;
         if (x0 + kbx * EB < w && y0 + kby * EB < h) bin_cnt[bin0 + (size_t)kby * g.bw + kbx] = s_n[tid];
-    }
-    {
-        const size_t bv = (size_t)b * NVAR + v;
-        const int hr = tid >> 2, hd = tid & 3;                        // row, dword of the block's H bits
-        if (y0 + hr < h && (x0 >> 5) + hd < ax_hw(g)) hbits[(bv * g.hmax + y0 + hr) * ax_hw(g) + (x0 >> 5) + hd] = s_hb[hr][hd];
-        const int vc = tid >> 1, vd = tid & 1;                        // column, dword of the block's V bits
-        if (x0 + vc < w) vbits[(bv * g.pitch + x0 + vc) * ax_vw(g) + (y0 >> 5) + vd] = s_vb[vc][vd];
     }
 }
 
@@ -218,34 +193,9 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
 // (same-address LDS atomics serialise, ~4 cycles per extra lane: profiles/r01_g_lds_atomic_microbench.txt).
 // (Measured: plain 32-bit cells halve the resident workgroups per CU and run 1.5x slower; a branch-free variant that
 // lets out-of-tile lanes add 0 to clamped cells runs 1.4x slower because of same-address conflicts.)
-//
-// Axis-aligned records (gradient exactly horizontal or vertical, see k_edge_bins) are NOT walked: the votes of such a pixel are
-// the cells x +- r of its row (y +- r of its column), r = min_r .. max_r, so what all of them together add to cell c of a row is
-// the number of marked pixels x of that row with min_r <= |c - x| <= max_r -- a popcount over a window of the row's bitmap.
-// After the walks the tile's part of the two bitmaps (+- 30 cells of reach) replaces the item rings in LDS; a cell's total is
-// its 16-bit counter plus the two window counts, evaluated LAZILY: a cell whose counter plus the populations of its whole
-// bitmap row and column (an upper bound of the window counts, kept in the unused 129th dword of the counter rows) does not
-// exceed the threshold cannot be a centre; the others -- a few hundred per tile -- get exact totals, they and their four
-// neighbours.  On a diagram that removes about half of all votes from the LDS-atomic path.
-constexpr int AXR = 30;          // reach kept in the LDS bitmaps = the largest max_r the host accepts
-constexpr int AXW = 6;           // dwords per bitmap row / column in LDS: VL + 2 * AXR = 188 bits
-static_assert(VL + 2 * AXR <= 32 * AXW && AXW * VL * 2 <= (VTHREADS / 64) * VRING, "the bitmaps take the place of the item rings");
-
-struct AxMasks { unsigned m_lo, m_hi, c_lo, c_hi; };   // window-relative masks: cells that get a vote, the centre (voted twice when min_r == 0)
-
-// votes of the marked pixels of one bitmap row (column) for the cell at bitmap position p (window = bits p - max_r .. p + max_r)
-__device__ __forceinline__ int ax_count(const unsigned* __restrict__ row, int p, int max_r, const AxMasks& am)
-{
-    const int s = p - max_r, k = s >> 5, sh = s & 31;
-    const unsigned w0 = row[k], w1 = row[imin(k + 1, AXW - 1)], w2 = row[imin(k + 2, AXW - 1)];
-    const unsigned lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    return __popc(lo & am.m_lo) + __popc(hi & am.m_hi) + __popc(lo & am.c_lo) + __popc(hi & am.c_hi);
-}
-
 template <int NSTEPS>
 __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict__ desc, Geo g,
                                                       const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
-                                                      const unsigned* __restrict__ hbits, const unsigned* __restrict__ vbits,
                                                       int min_r, int max_r, int acc_thr,
                                                       unsigned* __restrict__ cent_list, int* __restrict__ cent_count,
                                                       int* __restrict__ dbg_acc, int gx, int gy)
@@ -318,7 +268,7 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
         for (int k0 = 0; k0 < n_cur; k0 += 64) {
             if (k0 > 0) { mine = make_uint2(0u, 0u); if (k0 + lane < n_cur) mine = ent_cur[k0 + lane]; }
             bool reach_p = false, reach_n = false;
-            if (k0 + lane < n_cur && (mine.y & 0xffffu) != 0u && (mine.y >> 16) != 0u) {         // axis-aligned records: bitmaps
+            if (k0 + lane < n_cur) {
                 const int sxv = (int)(short)(mine.y & 0xffffu), syv = (int)(short)(mine.y >> 16);
                 const int exr = (int)(mine.x & 0xffffu) - vx_lo, eyr = (int)(mine.x >> 16) - vy_lo;
                 // the cells of direction +1 lie between the pixel and pixel + ((max_r * s) >> 10) on each axis (+-1 for the
@@ -357,90 +307,32 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
     }
     if (fill > 0) vote_walk64<NSTEPS>(ring, fill, lane, bin_ent, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
     __syncthreads();
-    // ---- axis-aligned votes: the tile's slice of the two bitmaps into the ring space
-    // s_hb[r][j]: bit i of the row = pixel x = lx0 - AXR + i of image row ly0 + r;  s_vb[c][j]: bit i = pixel y = ly0 - AXR + i of column lx0 + c
-    unsigned* s_hb = &s_ring[0][0];
-    unsigned* s_vb = s_hb + VL * AXW;
-    {
-        const int hw = ax_hw(g), vw = ax_vw(g);
-        const int dmax_h = (w + 31) >> 5, dmax_v = (h + 31) >> 5;
-        const unsigned* hb = hbits + (size_t)bv * g.hmax * hw;
-        const unsigned* vb = vbits + (size_t)bv * g.pitch * vw;
-        for (int i = tid; i < 2 * VL * AXW; i += VTHREADS) {
-            const bool vert = i >= VL * AXW;
-            const int ii = vert ? i - VL * AXW : i;
-            const int r = ii / AXW, j = ii - r * AXW;
-            // H: line = image row, positions = x;  V: line = image column, positions = y
-            const int line = (vert ? lx0 : ly0) + r, nline = vert ? w : h;
-            const int ps = (vert ? ly0 : lx0) - AXR + 32 * j;             // first position of this dword (may be negative)
-            const int d = ps >> 5, sh = ps & 31, dmax = vert ? dmax_v : dmax_h;
-            unsigned val = 0;
-            if (line >= 0 && line < nline) {
-                const unsigned* src = vert ? vb + (size_t)line * vw : hb + (size_t)line * hw;
-                const unsigned g0 = (d >= 0 && d < dmax) ? src[d] : 0u, g1 = (d + 1 >= 0 && d + 1 < dmax) ? src[d + 1] : 0u;
-                val = __builtin_amdgcn_alignbit(g1, g0, sh);
-            }
-            s_hb[i] = val;
-        }
-    }
-    __syncthreads();
-    // upper bounds: population of the whole row / column slice, one byte each, in the unused dword 128 of the counter rows:
-    // row r6 holds bh[r6], bh[r6 + 64], bv[2 r6], bv[2 r6 + 1]
-    if (tid < 2 * VL) {
-        const unsigned* rw = s_hb + tid * AXW;
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < AXW; j++) c += __popc(rw[j]);
-        uint8_t* sb = reinterpret_cast<uint8_t*>(s_acc);
-        if (tid < VL) sb[((tid & 63) * VASTR + VL) * 4 + (tid >> 6)] = (uint8_t)c;
-        else { const int cx = tid - VL; sb[((cx >> 1) * VASTR + VL) * 4 + 2 + (cx & 1)] = (uint8_t)c; }
-    }
-    __syncthreads();
-    AxMasks am;
-    {
-        // window bit i <-> cell distance i - max_r; voted iff min_r <= |distance| <= max_r (twice for distance 0 when min_r == 0)
-        unsigned long long m = 0ull;
-        for (int i = 0; i <= 2 * max_r; i++) { const int dd = i > max_r ? i - max_r : max_r - i; if (dd >= min_r) m |= 1ull << i; }
-        const unsigned long long c = min_r == 0 ? 1ull << max_r : 0ull;
-        am.m_lo = (unsigned)m; am.m_hi = (unsigned)(m >> 32); am.c_lo = (unsigned)c; am.c_hi = (unsigned)(c >> 32);
-    }
     // centre candidates: cells (x,y), 1 <= x <= w-1, 1 <= y <= h-1 (OpenCV scans padded rows 1..H, cols 1..W
     // of an accumulator whose votes sit at unpadded indices; cells x == W or y == H hold no votes).
     // tile cell (cx, cy): 16-bit half (cy >> 6) of dword (cy & 63) * VASTR + cx
 #define I2S_CELL(cx, cy) ((int)((s_acc[((cy) & 63) * VASTR + (cx)] >> (((cy) >> 6) * 16)) & 0xffffu))
-    // exact total of tile cell (cx, cy): walked votes + the two window counts; cells outside the image hold no votes
-    auto total = [&](int cx, int cy) -> int {
-        const int x = lx0 + cx, y = ly0 + cy;
-        if (x < 0 || x >= w || y < 0 || y >= h) return 0;
-        return I2S_CELL(cx, cy) + ax_count(s_hb + cy * AXW, cx + AXR, max_r, am) + ax_count(s_vb + cx * AXW, cy + AXR, max_r, am);
-    };
     if (dbg_acc) {
         for (int i = tid; i < VT * VT; i += VTHREADS) {
             const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
             const int x = lx0 + tx, y = ly0 + ty;
-            if (x < w && y < h) dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = total(tx, ty);
+            if (x < w && y < h) dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = I2S_CELL(tx, ty);
         }
     }
-    // one dword = cells (tx, r6) and (tx, r6 + 64): almost all stay below the threshold even with the bounds and are rejected in pairs
+    // one dword = cells (tx, r6) and (tx, r6 + 64): almost all hold fewer votes than the threshold and are rejected in pairs
     for (int i = tid; i < 64 * VT; i += VTHREADS) {
         const int r6 = i / VT, tx = i - r6 * VT + 1;
         const unsigned v2 = s_acc[r6 * VASTR + tx];
-        const unsigned bnd = s_acc[r6 * VASTR + VL];
-        const int bvx = (int)((s_acc[(tx >> 1) * VASTR + VL] >> (16 + 8 * (tx & 1))) & 0xffu) + (min_r == 0 ? 2 : 0);   // (centres count twice)
-        if ((int)(v2 & 0xffffu) + (int)(bnd & 0xffu) + bvx <= acc_thr && (int)(v2 >> 16) + (int)((bnd >> 8) & 0xffu) + bvx <= acc_thr) continue;
+        if ((int)(v2 & 0xffffu) <= acc_thr && (int)(v2 >> 16) <= acc_thr) continue;
         const int x = lx0 + tx;
         if (x >= w || x < 1) continue;
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int ty = r6 + 64 * hh;
             if (ty < 1 || ty > VT) continue;
+            const int a = hh ? (int)(v2 >> 16) : (int)(v2 & 0xffffu);
             const int y = ly0 + ty;
-            if (y >= h || y < 1) continue;
-            const int ub = (hh ? (int)(v2 >> 16) + (int)((bnd >> 8) & 0xffu) : (int)(v2 & 0xffffu) + (int)(bnd & 0xffu)) + bvx;
-            if (ub <= acc_thr) continue;
-            const int a = total(tx, ty);
-            if (a <= acc_thr) continue;
-            if (a > total(tx - 1, ty) && a >= total(tx + 1, ty) && a > total(tx, ty - 1) && a >= total(tx, ty + 1)) {
+            if (a <= acc_thr || y >= h || y < 1) continue;
+            if (a > I2S_CELL(tx - 1, ty) && a >= I2S_CELL(tx + 1, ty) && a > I2S_CELL(tx, ty - 1) && a >= I2S_CELL(tx, ty + 1)) {
                 const int k = atomicAdd(&cent_count[bv], 1);
                 if (k < g.cent_cap) cent_list[(size_t)bv * g.cent_cap + k] = (unsigned)x | ((unsigned)y << 16);
             }
