@@ -38,8 +38,11 @@ N_PIX = 1024 * 1024
 BLUR_CANNY_BYTES = 14 * N_PIX  # Canny 2N + 3 Gaussians 6N + 3 medians 6N, unfused accounting
 # conflict-free LDS-atomic ceiling of one MI355X (profiles/r01_g_lds_atomic_microbench.txt): 13.5 lanes per CU-cycle
 LDS_ATOMIC_PEAK = 13.5 * 256 * 2.4e9
-BLUR_CANNY_SEGS = ("k_grey", "k_median3", "k_median57", "k_gauss357", "k_blur", "k_sobel_nms(main Canny)",
+BLUR_CANNY_SEGS = ("k_grey", "k_median3", "k_median57_bin", "k_median57", "k_gauss357", "k_blur", "k_sobel_nms(main Canny)",
                    "k_hysteresis(main Canny)")
+CANNY7_SEGS = ("k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)")
+CANNY7_BYTES = 7 * 2 * N_PIX   # HoughCircles' internal Canny of the 7 planes that are not the grey plane: read N + write N each
+NOISE_SIGMA = 6.0              # SURVEY 8(d) config 2, variant "noisy": N(0, 6^2) added to the same diagrams, clipped
 
 
 def cpu_baseline(per_worker):
@@ -71,14 +74,14 @@ def measured_traffic():
     None -- not a stale number -- when the kernels changed since the counters were collected."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(p):
-        return None, {"file": None}
+        return None, None, {"file": None}
     with open(p) as f:
         t = json.load(f)
     src = {"file": "profiles/traffic.json", "kernels_sha_of_counters": t.get("kernels_sha"), "kernels_sha_now": kernels_sha()}
     if t.get("kernels_sha") != src["kernels_sha_now"]:
         src["stale"] = True
-        return None, src
-    return t.get("blur_canny_hbm_bytes_per_image"), src
+        return None, None, src
+    return t.get("blur_canny_hbm_bytes_per_image"), t.get("canny7_hbm_bytes_per_image"), src
 
 
 def self_launch(args):
@@ -196,10 +199,23 @@ def main():
         imgs = dev[:nv].cpu().numpy()
         d1.detect_batch(list(imgs), params, full=False)
         votes = sum(int(d1.fetch_circle_acc(i, v).sum()) for i in range(nv) for v in range(8)) / nv
+        # the noisy variant of the same diagrams (sigma = 6): every median band falls back to the bit-serial kernel, hysteresis
+        # has real work -- the headline fraction is the clean workload's, this is the honest companion
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        noisy = (dev[:nr].float() + torch.randn(dev[:nr].shape, device="cuda", generator=gen) * NOISE_SIGMA).clamp(0, 255).to(torch.uint8)
+        d1.set_debug(False)
+        d1.detect_device(noisy, params)
+        d1.detect_device(noisy, params)
+        seg_noisy = d1.last_kernel_timing()
+        del noisy
         d1.close()
         stage_s = sum(seg.get(k, 0.0) for k in BLUR_CANNY_SEGS) * 1e-3
+        stage_noisy_s = sum(seg_noisy.get(k, 0.0) for k in BLUR_CANNY_SEGS) * 1e-3
+        canny7_s = sum(seg.get(k, 0.0) for k in CANNY7_SEGS) * 1e-3
         ach = BLUR_CANNY_BYTES * nr / stage_s / 1e9
-        traffic, traffic_src = measured_traffic()
+        ach_noisy = BLUR_CANNY_BYTES * nr / stage_noisy_s / 1e9
+        ach7 = CANNY7_BYTES * nr / canny7_s / 1e9
+        traffic, traffic7, traffic_src = measured_traffic()
         vote_s = seg["k_vote_centres"] * 1e-3
         images = total * args.steps
         out = {
@@ -210,7 +226,8 @@ def main():
                                    "device-resident, full hot path incl. board all-gather" % (B, 2 if world == 1 else 3),
                        "pass_size": pass_size, "streams": args.streams, "boards_match_generator": ok,
                        "rccl_ranks": world if use_dist else 0,
-                       "allgather": "ncclAllGather of device-resident records through the C ABI" if use_dist else "single process: none"},
+                       "allgather": "ncclAllGather of device-resident records through the C ABI" if use_dist else "single process: none",
+                       "allgather_in_place": bool(gather.in_place()) if gather is not None else None},
             "roofline": {"bound": "hbm",
                          "kernel": "blur+Canny stage: " + ", ".join(k for k in BLUR_CANNY_SEGS if k in seg),
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -218,6 +235,15 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,
                          "stage_us_per_image": stage_s / nr * 1e6,
                          "measured_on": "1 stream, %d diagrams, HIP events on the context's stream in front of every kernel" % nr},
+            "roofline_noisy": {"bound": "hbm", "kernel": "blur+Canny stage on the noisy variant of the workload (N(0, %g^2) added, clipped)" % NOISE_SIGMA,
+                               "achieved": ach_noisy, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_noisy / HBM_PEAK_GBS,
+                               "traffic": None, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,
+                               "stage_us_per_image": stage_noisy_s / nr * 1e6,
+                               "kernel_us_per_image": {k: seg_noisy[k] * 1e3 / nr for k in BLUR_CANNY_SEGS if k in seg_noisy}},
+            "roofline_canny7": {"bound": "hbm", "kernel": "HoughCircles' internal Canny of 7 planes: " + ", ".join(CANNY7_SEGS),
+                                "achieved": ach7, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach7 / HBM_PEAK_GBS,
+                                "traffic": traffic7, "algorithmic_bytes_per_image": CANNY7_BYTES,
+                                "us_per_image": canny7_s / nr * 1e6},
             "roofline_k5": {"bound": "lds-atomic", "kernel": "k_vote_centres (HoughCircles accumulator, 8 variants per image)",
                             "votes_per_image": votes, "achieved": votes * nr / vote_s, "peak": LDS_ATOMIC_PEAK, "unit": "votes/s",
                             "frac": votes * nr / vote_s / LDS_ATOMIC_PEAK,

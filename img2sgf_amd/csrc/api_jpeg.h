@@ -494,9 +494,23 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
         hipLaunchKernelGGL(k_jpeg_idct, dim3(cdiv(max_blocks, 64), nb), dim3(64), 0, ctx->stream, ctx->d_jd);
         hipLaunchKernelGGL(k_jpeg_rgb, dim3(cdiv(wmax, 64), cdiv(hmax, 4), nb), dim3(64, 4), 0, ctx->stream, ctx->d_jd);
         // the decoded images are device-resident sources of the ordinary path
+        // The inner call sees pass-local image indices 0 .. nb - 1: with the caller's board sink in place it would write every
+        // pass's records to sink[0 .. nb).  The sink is taken away for the call and the pass's records (still in d_boards) are
+        // delivered afterwards to sink[input index], on the stream, before anything can overwrite d_boards.
+        i2s_board* const sink = ctx->d_sink;
+        ctx->d_sink = nullptr;
         rc = i2s_detect_batch_xf(ctx, nb, ptr.data(), pw.data(), ph.data(), ps.data(), pc.data(), xf ? pxf.data() : nullptr, &pd,
                                  pb.data(), full ? pf.data() : nullptr);
+        ctx->d_sink = sink;
         if (rc) return rc;
+        if (sink) {
+            bool dense = true;
+            for (int i = 1; i < nb; i++) dense &= order[first + i] == order[first] + i;
+            if (dense) I2S_HIP(hipMemcpyAsync(sink + order[first], ctx->d_boards, (size_t)nb * sizeof(i2s_board), hipMemcpyDeviceToDevice, ctx->stream));
+            else for (int i = 0; i < nb; i++)
+                I2S_HIP(hipMemcpyAsync(sink + order[first + i], ctx->d_boards + i, sizeof(i2s_board), hipMemcpyDeviceToDevice, ctx->stream));
+            I2S_HIP(hipStreamSynchronize(ctx->stream));
+        }
         for (int i = 0; i < nb; i++) {
             boards[order[first + i]] = pb[i];
             if (full) full[order[first + i]] = pf[i];

@@ -31,13 +31,18 @@ struct RcclApi {
 static void rccl_open(RcclApi& api);
 
 // the library is opened once per process, whichever thread asks first
-static RcclApi* rccl_api()
+static RcclApi& rccl_state()
 {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] { rccl_open(api); });
-    return api.handle ? &api : nullptr;
+    return api;
 }
+static RcclApi* rccl_api() { RcclApi& a = rccl_state(); return a.handle ? &a : nullptr; }
+static const char* rccl_open_error() { return rccl_state().err; }
+
+// why rccl_api() returned null
+static const char* rccl_open_error();
 
 static void rccl_open(RcclApi& api)
 {

@@ -873,19 +873,10 @@ extern "C" int i2s_set_board_sink(i2s_ctx* ctx, i2s_board* d_sink)
     return I2S_OK;
 }
 
-extern "C" int i2s_comm_unique_id(uint8_t id[I2S_COMM_ID_BYTES])
-{
-    if (!id) return I2S_E_INVALID;
-    RcclApi* api = rccl_api();
-    if (!api) return I2S_E_NO_DEVICE;
-    RcclId u;
-    memset(&u, 0, sizeof(u));
-    if (api->GetUniqueId(&u) != 0) return I2S_E_HIP;
-    memcpy(id, u.internal, I2S_COMM_ID_BYTES);
-    return I2S_OK;
-}
+// text of the last failure of a call that has no communicator to hang it on (i2s_comm_unique_id, i2s_comm_create), per thread
+static thread_local char g_comm_err[256] = "no error";
 
-extern "C" const char* i2s_comm_last_error(const i2s_comm* comm) { return comm ? comm->err : "null communicator"; }
+extern "C" const char* i2s_comm_last_error(const i2s_comm* comm) { return comm ? comm->err : g_comm_err; }
 
 extern "C" void i2s_comm_destroy(i2s_comm* comm)
 {
@@ -897,6 +888,26 @@ extern "C" void i2s_comm_destroy(i2s_comm* comm)
     delete comm;
 }
 
+static RcclApi* rccl_api_or_error()
+{
+    RcclApi* api = rccl_api();
+    if (!api) snprintf(g_comm_err, sizeof(g_comm_err), "%s", rccl_open_error());
+    return api;
+}
+
+extern "C" int i2s_comm_unique_id(uint8_t id[I2S_COMM_ID_BYTES])
+{
+    if (!id) return I2S_E_INVALID;
+    RcclApi* api = rccl_api_or_error();
+    if (!api) return I2S_E_NO_DEVICE;
+    RcclId u;
+    memset(&u, 0, sizeof(u));
+    const int r = api->GetUniqueId(&u);
+    if (r != 0) { snprintf(g_comm_err, sizeof(g_comm_err), "ncclGetUniqueId failed: %s", api->GetErrorString(r)); return I2S_E_HIP; }
+    memcpy(id, u.internal, I2S_COMM_ID_BYTES);
+    return I2S_OK;
+}
+
 extern "C" int i2s_comm_create(i2s_comm** out, int device_id, const uint8_t id[I2S_COMM_ID_BYTES], int world, int rank, int records_per_rank)
 {
     if (!out || !id || device_id < 0 || world < 1 || rank < 0 || rank >= world || records_per_rank < 1 ||
@@ -904,20 +915,28 @@ extern "C" int i2s_comm_create(i2s_comm** out, int device_id, const uint8_t id[I
         return I2S_E_INVALID;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id >= ndev) return I2S_E_NO_DEVICE;
-    RcclApi* api = rccl_api();
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id >= ndev) { snprintf(g_comm_err, sizeof(g_comm_err), "no HIP device %d", device_id); return I2S_E_NO_DEVICE; }
+    RcclApi* api = rccl_api_or_error();
     if (!api) return I2S_E_NO_DEVICE;
-    if (hipSetDevice(device_id) != hipSuccess) return I2S_E_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) { snprintf(g_comm_err, sizeof(g_comm_err), "hipSetDevice(%d) failed", device_id); return I2S_E_NO_DEVICE; }
     i2s_comm* c = new i2s_comm();
     c->device = device_id; c->world = world; c->rank = rank; c->cap = records_per_rank;
+    // The gather buffer first, but a rank whose allocation fails STILL enters ncclCommInitRank: the call is collective, and a rank
+    // that returned early would leave its peers waiting in it for ever.  The failure is reported after the rendezvous.
     const size_t bytes = (size_t)world * records_per_rank * sizeof(i2s_board);
-    if (hipMalloc(&c->d_all, bytes) != hipSuccess || hipMemset(c->d_all, 0, bytes) != hipSuccess) { i2s_comm_destroy(c); return I2S_E_HIP; }
+    hipError_t he = hipMalloc(&c->d_all, bytes);
+    if (he == hipSuccess) he = hipMemset(c->d_all, 0, bytes);
     RcclId u;
     memcpy(u.internal, id, I2S_COMM_ID_BYTES);
     const int r = api->CommInitRank(&c->comm, world, u, rank);       // collective: every rank of the job calls it
     if (r != 0) {
-        fprintf(stderr, "i2s_comm_create: ncclCommInitRank failed: %s\n", api->GetErrorString(r));
+        snprintf(g_comm_err, sizeof(g_comm_err), "ncclCommInitRank failed: %s", api->GetErrorString(r));
         c->comm = nullptr;
+        i2s_comm_destroy(c);
+        return I2S_E_HIP;
+    }
+    if (he != hipSuccess) {
+        snprintf(g_comm_err, sizeof(g_comm_err), "gather buffer of %zu bytes: %s", bytes, hipGetErrorString(he));
         i2s_comm_destroy(c);
         return I2S_E_HIP;
     }
@@ -937,9 +956,15 @@ extern "C" int i2s_allgather_boards(i2s_ctx* ctx, i2s_comm* comm, const i2s_boar
     i2s_board* shard = i2s_comm_shard(comm);
     if (!d_boards) d_boards = shard;
     if (!d_all) d_all = comm->d_all;
-    // every rank sends comm->cap records (shards differ by at most one image); the unused tail of the own shard is zeroed
-    if (d_boards == shard && n_local < comm->cap)
+    // every rank sends comm->cap records (shards differ by at most one image).  Records handed in from elsewhere are first copied
+    // into the own shard -- the caller's array need only hold n_local of them -- and the unused tail of the shard is zeroed.
+    if (d_boards != shard) {
+        if (n_local > 0) I2S_HIP(hipMemcpyAsync(shard, d_boards, (size_t)n_local * sizeof(i2s_board), hipMemcpyDeviceToDevice, ctx->stream));
+        d_boards = shard;
+    }
+    if (n_local < comm->cap)
         I2S_HIP(hipMemsetAsync(shard + n_local, 0, (size_t)(comm->cap - n_local) * sizeof(i2s_board), ctx->stream));
+    // in place (sendbuff == recvbuff + rank * count) when the result goes to the communicator's own buffer
     const int r = api->AllGather(d_boards, d_all, (size_t)comm->cap * sizeof(i2s_board), 1 /* ncclUint8 */, comm->comm, ctx->stream);
     if (r != 0) {
         snprintf(ctx->err, sizeof(ctx->err), "ncclAllGather failed: %s", api->GetErrorString(r));

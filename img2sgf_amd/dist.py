@@ -82,7 +82,8 @@ class BoardGather:
         idb = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(uid))
         rc = self.lib.dll.i2s_comm_create(C.byref(self._comm), device, idb, world, rank, self.cap)
         if rc != 0:
-            raise I2sError("i2s_comm_create failed: %s" % self.lib.dll.i2s_strerror(rc).decode())
+            raise I2sError("i2s_comm_create failed: %s: %s" % (self.lib.dll.i2s_strerror(rc).decode(),
+                                                              self.lib.dll.i2s_comm_last_error(None).decode()))
         self.shard_ptr = int(self.lib.dll.i2s_comm_shard(self._comm))     # device address of this rank's records
         self.all_ptr = int(self.lib.dll.i2s_comm_all(self._comm))
         self._host = np.zeros((world * self.cap, BOARD_BYTES), np.uint8)
@@ -93,8 +94,12 @@ class BoardGather:
         idb = (C.c_uint8 * _lib.COMM_ID_BYTES)()
         rc = lib.dll.i2s_comm_unique_id(idb)
         if rc != 0:
-            raise I2sError("i2s_comm_unique_id failed: %s" % lib.dll.i2s_strerror(rc).decode())
+            raise I2sError("i2s_comm_unique_id failed: %s: %s" % (lib.dll.i2s_strerror(rc).decode(), lib.dll.i2s_comm_last_error(None).decode()))
         return bytes(idb)
+
+    def in_place(self):
+        """True when the all-gather of the shard is the in-place form NCCL/RCCL documents: sendbuff == recvbuff + rank * count."""
+        return self.shard_ptr == self.all_ptr + self.rank * self.cap * BOARD_BYTES
 
     def sink(self, first=0):
         """Device address where the record of this rank's image `first` belongs (for Detector.set_board_sink)."""

@@ -299,6 +299,9 @@ class Detector:
         assert batch.is_cuda and batch.is_contiguous() and str(batch.dtype) == "torch.uint8"
         B, H, W = batch.shape[:3]
         cn = 1 if batch.dim() == 3 else 3
+        # single-channel sources with dword-aligned rows ARE their grey planes (no copy): classify() and fetch_plane("grey")
+        # read these pixels after the call has returned, so the tensor must outlive it -- until the next detect call
+        self._last_batch = batch
         base, step = batch.data_ptr(), H * W * cn
         boards, _ = self.detect_ptrs([base + i * step for i in range(B)], [W] * B, [H] * B, [W * cn] * B, [cn] * B,
                                      params, True, False)

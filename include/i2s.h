@@ -121,7 +121,7 @@ typedef struct i2s_params {
     int32_t gauss_kernel_mode;         /* 0 = error-diffused taps summing to 256 | 1 = plain rounding */
     int32_t houghlines_numangle_mode;  /* 0 = floor+1 with pi-wrap fix (current) | 1 = cvRound (legacy) */
     int32_t inputs_on_device;          /* 1: img[] are device pointers, read IN PLACE (no copy): a single-channel image with 4-byte
-                                          aligned rows also serves as its own grey plane, so it must stay valid and unchanged until
+                                          aligned rows and a width that is a multiple of 4 also serves as its own grey plane: it must stay valid and unchanged until
                                           the next detect call if i2s_classify_batch / i2s_fetch_plane(GREY) are used on it;
                                           0: host pointers (staged into the context) */
     /* Pillow pre-processing on the device (img2sgf.py:141-149): contrast / brightness slider values 0..100, the
@@ -280,10 +280,13 @@ int  i2s_last_timing(const i2s_ctx* ctx, float ms[5]);
  *                the shard without touching the host;
  *                i2s_allgather_boards(ctx, comm, d_boards, n_local, d_all, h_all) -- ncclAllGather on ctx's stream of
  *                records_per_rank records per rank from d_boards (NULL = the shard: in place) into d_all (NULL = the
- *                communicator's buffer); n_local <= records_per_rank of them are valid on this rank (the tail of the own
- *                shard is zeroed); h_all, if not NULL, receives a host copy of all [world][records_per_rank] records.
+ *                communicator's buffer); d_boards need only hold the n_local <= records_per_rank records that are valid on
+ *                this rank (records from elsewhere are copied into the shard first; the tail of the shard is zeroed); h_all,
+ *                if not NULL, receives a host copy of all [world][records_per_rank] records.
  *                Synchronous on return.  Rank r's records are those of images shard_range(total, r, world).
- * librccl is opened with dlopen on first use; I2S_E_NO_DEVICE if it is missing. */
+ * librccl is opened with dlopen on first use; I2S_E_NO_DEVICE if it is missing.  i2s_comm_create is collective even in failure:
+ * a rank whose local allocation fails still takes part in ncclCommInitRank and reports afterwards.
+ * i2s_comm_last_error(NULL) = text of this thread's last failed i2s_comm_unique_id / i2s_comm_create (dlopen, RCCL, HIP). */
 #define I2S_COMM_ID_BYTES 128
 typedef struct i2s_comm i2s_comm;
 int  i2s_comm_unique_id(uint8_t id[I2S_COMM_ID_BYTES]);

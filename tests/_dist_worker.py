@@ -1,4 +1,4 @@
-"""Worker of tests/test_dist_gloo.py: one rank of a 2-process gloo job.  Each rank detects its shard of a small
+"""Worker of tests/test_dist_gloo.py: one rank of an N-process gloo job (N = WORLD_SIZE: 2 or 8).  Each rank detects its shard of a small
 synthetic batch and all-gathers the boards over gloo (host tensors).  argv[3] == "emu": the emulated build of the
 product sources (no GPU in the build container); "hip": the real library on GPU 0 -- both ranks share the one leased
 GPU, which is why this job cannot use RCCL (it refuses two ranks on one device)."""
@@ -25,7 +25,8 @@ def main():
     imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(lo, hi)]
     lib = emu_util.emu_library() if sys.argv[3] == "emu" else None
     det = Detector(0, 2, 300, 260, lib=lib)
-    boards = det.detect_batch(imgs, full=False)
+    from img2sgf_amd._lib import I2sBoard
+    boards = det.detect_batch(imgs, full=False) if imgs else (I2sBoard * 0)()      # a rank may own no image (total < world)
     allb = i2s_dist.allgather_boards_host(boards, total, rank, world)
     assert allb.shape == (total, 384)
     np.save(os.path.join(out, "rank%d.npy" % rank), allb)

@@ -37,16 +37,20 @@ def test_compact_and_records_per_rank():
         assert (out[:, 0] == np.arange(total) % 251 + 1).all()
 
 
-def _two_ranks(tmp_path, total, mode, port):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+def _ranks(tmp_path, total, mode, port, world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(total), str(tmp_path), mode],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
     for p in procs:
-        assert p.wait(timeout=600) == 0
+        assert p.wait(timeout=900) == 0
     a = np.load(tmp_path / "rank0.npy")
-    b = np.load(tmp_path / "rank1.npy")
-    np.testing.assert_array_equal(a, b)
+    for r in range(1, world):
+        np.testing.assert_array_equal(a, np.load(tmp_path / ("rank%d.npy" % r)))
     return a
+
+
+def _two_ranks(tmp_path, total, mode, port):
+    return _ranks(tmp_path, total, mode, port, 2)
 
 
 def test_two_rank_allgather(tmp_path):
@@ -59,6 +63,98 @@ def test_two_rank_allgather(tmp_path):
     np.testing.assert_array_equal(a, single)
     for s in range(total):
         assert (a[s, :361].reshape(19, 19)[:9, :8] == synth.occupancy(s, 9, 8)).all()
+
+
+@pytest.mark.parametrize("total", [11, 5])
+def test_eight_rank_allgather_uneven_shards(tmp_path, total):
+    """BASELINE configs[3]'s shape -- 8 ranks -- on CPU over gloo with the emulated kernels: total % 8 != 0, so the shards
+    differ in size (11 -> 2,2,2,1,1,1,1,1; 5 -> three ranks own nothing), every rank sends records_per_rank records with a zeroed
+    tail, compact() must drop the padding, and all eight tables must equal the single-process run."""
+    emu_util.emu_library()
+    a = _ranks(tmp_path, total, "emu", 29621 + total, 8)
+    assert a.shape == (total, 384)
+    det = Detector(0, 2, 300, 260, lib=emu_util.emu_library())
+    imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(total)]
+    single = i2s_dist.boards_to_numpy(det.detect_batch(imgs, full=False))
+    np.testing.assert_array_equal(a, single)
+
+
+class _FakeCommDll:
+    """Stand-in for the i2s_comm_* entry points of libi2s_hip.so: eight "ranks" in one process, each with its own
+    [world][cap] gather buffer in host memory; i2s_allgather_boards copies every rank's shard into the caller's buffer the way
+    ncclAllGather does (rank r's count records at recvbuff + r * count).  Checks dist.BoardGather's address arithmetic
+    without a GPU: nothing here computes."""
+    def __init__(self, world, cap):
+        import ctypes as C
+        self.C, self.world, self.cap = C, world, cap
+        self.bufs = [np.zeros((world, cap, 384), np.uint8) for _ in range(world)]
+        self.handles = {}
+
+    def i2s_comm_create(self, out, device, idb, world, rank, cap):
+        assert (world, cap) == (self.world, self.cap) and 0 <= rank < world
+        h = 1000 + rank
+        self.handles[h] = rank
+        out._obj.value = h
+        return 0
+
+    def _rank(self, comm):
+        return self.handles[comm.value if hasattr(comm, "value") else int(comm)]
+
+    def i2s_comm_all(self, comm):
+        return self.bufs[self._rank(comm)].ctypes.data
+
+    def i2s_comm_shard(self, comm):
+        r = self._rank(comm)
+        return self.bufs[r].ctypes.data + r * self.cap * 384
+
+    def i2s_allgather_boards(self, ctx, comm, d_boards, n_local, d_all, h_all):
+        assert d_boards is None and d_all is None                  # the in-place form
+        me = self._rank(comm)
+        assert 0 <= n_local <= self.cap
+        self.bufs[me][me, n_local:] = 0                             # the library zeroes the unused tail of the own shard
+        for r in range(self.world):
+            self.bufs[me][r] = self.bufs[r][r]                      # ncclAllGather: rank r's records at r * count
+        if h_all is not None:
+            self.C.memmove(h_all, self.bufs[me].ctypes.data, self.bufs[me].nbytes)
+        return 0
+
+    def i2s_comm_destroy(self, comm):
+        return None
+
+
+def test_board_gather_offsets_world8_with_fake_comm():
+    """BoardGather with world = 8 and uneven shards against a fake i2s_comm: the sink address of image k of rank r, the
+    records_per_rank every rank sends, the in-place relation sendbuff == recvbuff + rank * count, and the image-order table
+    that comes out -- so that the first real `python bench.py --gpus 8` cannot fail on indexing."""
+    import ctypes as C
+    total, world = 29, 8                                            # shards 4,4,4,4,4,3,3,3
+    cap = i2s_dist.records_per_rank(total, world)
+    assert cap == 4
+    dll = _FakeCommDll(world, cap)
+    lib = type("FakeLib", (), {"dll": dll})()
+    gathers = [i2s_dist.BoardGather(0, world, r, total, bytes(128), lib=lib) for r in range(world)]
+    for r, g in enumerate(gathers):
+        lo, hi = i2s_dist.shard_range(total, r, world)
+        assert (g.lo, g.hi, g.cap) == (lo, hi, cap) and g.in_place()
+        assert g.shard_ptr - g.all_ptr == r * cap * 384
+        # a stale record beyond the shard's valid part must not survive the gather
+        C.memset(g.sink(0), 0xEE, cap * 384)
+        for k in range(lo, hi):                                     # what Detector.detect_device(..., sink=g.sink(first)) does on the device
+            rec = np.full(384, 0, np.uint8)
+            rec[0], rec[1], rec[383] = k % 251 + 1, r + 1, 0x5A
+            C.memmove(g.sink(k - lo), rec.ctypes.data, 384)
+    det = type("FakeDetector", (), {"_ctx": None})()
+    tables = [g.allgather(det) for g in gathers]
+    for t in tables:
+        assert t.shape == (total, 384)
+        np.testing.assert_array_equal(t, tables[0])
+    t = tables[3]                                                   # rank 3's view
+    assert (t[:, 0] == np.arange(total) % 251 + 1).all() and (t[:, 383] == 0x5A).all()
+    owner = np.concatenate([np.full(i2s_dist.shard_range(total, r, world)[1] - i2s_dist.shard_range(total, r, world)[0], r + 1)
+                            for r in range(world)])
+    assert (t[:, 1] == owner).all()
+    for g in gathers:
+        g.close()
 
 
 @pytest.mark.gpu

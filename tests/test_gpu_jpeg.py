@@ -291,3 +291,28 @@ def test_non_interleaved_sequential_scans(on_device):
     for k, r in enumerate(refs):
         np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d" % k)
     det.close()
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_board_sink_with_more_files_than_one_pass(schedule):
+    """i2s.h: with a board sink set, image i's record lands at sink[i] -- also when the JPEG batch needs several device passes
+    (each pass calls the ordinary path with pass-local indices) and when the passes are formed by area (schedule)."""
+    import ctypes as C
+    import torch
+    from img2sgf_amd._lib import I2sBoard
+    names = ["ex1.jpg", "ex9.jpg", "ex7.jpg", "ex2.jpg", "no_circles.jpg", "ex12.jpg", "ex5.jpg"]
+    blobs = [_blob(n) for n in names]
+    sizes = [Image.open(io.BytesIO(b)).size for b in blobs]
+    det = Detector(0, 3, max(s[0] for s in sizes), max(s[1] for s in sizes))      # 7 files, 3 per pass
+    nbytes = C.sizeof(I2sBoard)
+    sink = torch.full((len(names) + 1, nbytes), 0xEE, dtype=torch.uint8, device="cuda")
+    det.set_board_sink(sink.data_ptr())
+    boards = det.detect_jpeg(blobs, Params(schedule=schedule), full=False)
+    det.set_board_sink(None)
+    torch.cuda.synchronize()
+    got = sink.cpu().numpy()
+    for k, n in enumerate(names):
+        want = np.frombuffer(bytes(boards[k]), dtype=np.uint8)
+        np.testing.assert_array_equal(got[k], want, err_msg="sink[%d] (%s)" % (k, n))
+    assert (got[len(names)] == 0xEE).all()                                        # nothing past the batch was touched
+    det.close()
