@@ -191,3 +191,67 @@ def compare(img, compat, threshold=None):
     same("HoughLines H :236", orc["hlines"], ref["hlines"])
     same("HoughLines V :240-247", orc["vlines"], ref["vlines"])
     return bad
+
+
+# ---- digest check: python -m oracle.cv2_harness --digests ---------------------------------------------------------------------
+
+def check_digests(digest_file=None, fixture_dir=None, out=print):
+    """Runs the reference's ten calls on the installed cv2 over the committed digest set and compares each stage's digest with
+    what oracle/ answered (tests/golden/oracle_stage_digests.json).  Needs numpy, Pillow and cv2 only.  Returns the list of
+    (input, stage) that differ under the default switch set; prints the A.7 switch value each directly affected stage matches."""
+    import os
+    import cv2
+    from . import stage_digests as sd
+    doc = sd.load(digest_file)
+    fixture_dir = fixture_dir or os.path.join(os.path.dirname(sd.DIGEST_FILE), "test_images")
+    out("cv2 %s; oracle digests: %d inputs, switches %s" % (cv2.__version__, len(doc["inputs"]), doc["switches"]))
+    bad, votes = [], {"grey_shift": {}, "gauss_kernel_mode": {}, "houghlines_numangle": {}}
+
+    def vote(switch, value):
+        votes[switch][value] = votes[switch].get(value, 0) + 1
+
+    for name, img in sd.inputs(fixture_dir):
+        e = doc["inputs"].get(name)
+        if e is None:
+            continue
+        if sd.sha(img, np.uint8) != e["input"]:
+            out("%-16s INPUT differs (another Pillow / libjpeg decodes or enhances these pixels differently): skipped" % name)
+            continue
+        got = sd.stage_digests(run_cv2_calls(img, e["threshold"]))
+        for stage, want in e["stages"].items():
+            if got[stage] == want:
+                continue
+            alts = [k for k, v in e["alt"].items() if k.startswith(stage + "@") and v == got[stage]]
+            bad.append((name, stage, alts[0].split("@")[1] if alts else None))
+        # which switch value does this cv2 match on the directly affected stages?
+        if img.ndim == 3:
+            vote("grey_shift", 15 if got["cvtColor:153"] == e["stages"]["cvtColor:153"] else
+                 (14 if got["cvtColor:153"] == e["alt"].get("cvtColor:153@grey_shift=14") else "neither"))
+        for k in (3, 5, 7):
+            st = "gauss%d:174-175" % k
+            if got["cvtColor:153"] == e["stages"]["cvtColor:153"]:            # same grey plane into GaussianBlur
+                vote("gauss_kernel_mode", 0 if got[st] == e["stages"][st] else (1 if got[st] == e["alt"][st + "@gauss_kernel_mode=1"] else "neither"))
+        for st in ("HoughLines_H:236", "HoughLines_V:240-247"):
+            if got["erase:191-198"] == e["stages"]["erase:191-198"]:          # same input image to HoughLines
+                vote("houghlines_numangle", 0 if got[st] == e["stages"][st] else
+                     (1 if got[st] == e["alt"][st + "@houghlines_numangle=1"] else "neither"))
+    out("switch values matched (value: number of stages): %s" % votes)
+    for name, stage, alt in bad:
+        out("DIFFERS %-16s %-28s%s" % (name, stage, "  (matches the oracle under %s)" % alt if alt else ""))
+    out("%d of the compared stages differ under the default switch set" % len(bad) if bad else "every compared stage is byte-identical: rows a2-a8 pinned for this cv2")
+    return bad
+
+
+if __name__ == "__main__":
+    import argparse
+    import sys
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--digests", action="store_true", help="compare the installed cv2 with the committed oracle digests")
+    ap.add_argument("--file", default=None)
+    ap.add_argument("--fixtures", default=None)
+    a = ap.parse_args()
+    if a.digests:
+        if not have_cv2():
+            sys.exit("cv2 is not importable here: nothing to compare")
+        sys.exit(1 if check_digests(a.file, a.fixtures) else 0)
+    ap.print_help()

@@ -60,3 +60,17 @@ def test_harness_runs_and_selects_switches(monkeypatch, switches):
     r = H.cv2_process_image(img)
     assert r["board_ready"] and r["sgf"].startswith("(;GM[1]FF[4]SZ[19]")
     assert H.compare(np.zeros((40, 50), np.uint8), c) == []          # no circles, no lines: the None / empty paths
+
+
+@pytest.mark.parametrize("switches,expect_bad", [((15, 0, 0), False), ((14, 1, 1), True)])
+def test_digest_check_runs(monkeypatch, switches, expect_bad):
+    """python -m oracle.cv2_harness --digests, with the oracle-backed stand-in as "cv2": under the default switches every digest
+    matches; a stand-in that behaves like an older OpenCV is reported stage by stage, with the switch value it matches."""
+    monkeypatch.setitem(sys.modules, "cv2", _oracle_backed_module(*switches))
+    from oracle import cv2_harness as H
+    lines = []
+    bad = H.check_digests(out=lines.append)
+    assert bool(bad) == expect_bad
+    if expect_bad:
+        assert any(b[2] == "gauss_kernel_mode=1" for b in bad) and any(b[2] == "grey_shift=14" for b in bad)
+        assert "neither" not in lines[1]

@@ -126,3 +126,84 @@ def test_ex1_known_answer():
     assert r["threshold"] == 74
     assert (r["num_black_stones"], r["num_white_stones"]) == (9, 5)
     assert r["sgf"] == EX1_SGF
+
+
+# ---- independent implementations (scipy is in the image; cv2 is not) --------------------------------------------------------
+
+def _awkward_images():
+    rng = np.random.default_rng(5)
+    yield rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    yield np.where(rng.random((40, 41)) < 0.5, 0, 255).astype(np.uint8)              # two-valued (the diagrams)
+    yield (rng.integers(0, 4, (29, 64)) * 85).astype(np.uint8)                        # few levels
+    yield rng.integers(0, 256, (1, 9), dtype=np.uint8)
+    yield rng.integers(0, 256, (9, 1), dtype=np.uint8)
+    yield rng.integers(0, 256, (2, 2), dtype=np.uint8)
+
+
+def test_median_against_scipy():
+    """cv.medianBlur (img2sgf.py:174) = exact median with BORDER_REPLICATE = scipy.ndimage.median_filter(mode='nearest')."""
+    from scipy import ndimage
+    for img in _awkward_images():
+        for k in (3, 5, 7):
+            np.testing.assert_array_equal(cvo.median_blur(img, k), ndimage.median_filter(img, size=k, mode="nearest"),
+                                          err_msg="k=%d shape %s" % (k, img.shape))
+
+
+def test_sobel_against_scipy():
+    """The Sobel 3x3 of Canny / HoughCircles (CV_16S, BORDER_REPLICATE) = correlation with the Sobel kernels, mode 'nearest'."""
+    from scipy import ndimage
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], np.int32)
+    for img in _awkward_images():
+        dx, dy = cvo.sobel3(img)
+        i32 = img.astype(np.int32)
+        np.testing.assert_array_equal(dx, ndimage.correlate(i32, kx, mode="nearest"))
+        np.testing.assert_array_equal(dy, ndimage.correlate(i32, kx.T, mode="nearest"))
+
+
+def test_gaussian_against_scipy():
+    """cv.GaussianBlur 8-bit fixed-point path (img2sgf.py:175): integer taps, BORDER_REFLECT_101 (= scipy 'mirror'),
+    (sum + 32768) >> 16 -- recomputed with scipy's separable correlation in int64."""
+    from scipy import ndimage
+    for img in _awkward_images():
+        for k in (3, 5, 7):
+            taps = cvo.gauss_kernel_q8(k, k).astype(np.int64)
+            t = ndimage.correlate1d(img.astype(np.int64), taps, axis=1, mode="mirror")
+            a = ndimage.correlate1d(t, taps, axis=0, mode="mirror")
+            np.testing.assert_array_equal(cvo.gaussian_blur(img, k, k), ((a + 32768) >> 16).astype(np.uint8),
+                                          err_msg="k=%d shape %s" % (k, img.shape))
+
+
+def test_grey_against_numpy():
+    rng = np.random.default_rng(6)
+    rgb = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8).astype(np.int64)
+    want = (rgb[..., 0] * 3735 + rgb[..., 1] * 19235 + rgb[..., 2] * 9798 + 16384) >> 15
+    np.testing.assert_array_equal(cvo.bgr2gray(rgb.astype(np.uint8)), want.astype(np.uint8))
+
+
+def test_hough_lines_row_and_column_counts():
+    """At theta = pi/2 (sin = 1, |cos| < 1e-7) rho is the row index and at theta = 0 the column index: the accumulators of those
+    angles are plain row / column counts of the non-zero pixels."""
+    import math
+    rng = np.random.default_rng(8)
+    img = (rng.random((50, 70)) < 0.2).astype(np.uint8) * 255
+    d = math.pi / 180
+    _, dbg = cvo.hough_lines(img, 1, d, 1, 0.0, d, 0, debug=True)
+    numrho = 2 * (50 + 70) + 1
+    acc = np.asarray(dbg["acc"]).reshape(-1, numrho + 2)
+    cols = (img != 0).sum(axis=0)
+    np.testing.assert_array_equal(acc[1, 1 + (numrho - 1) // 2: 1 + (numrho - 1) // 2 + 70], cols)
+
+
+# ---- committed digests of the oracle's answers (tests/golden/oracle_stage_digests.json) ---------------------------------------
+
+def test_oracle_matches_its_committed_digests():
+    """The digest file any cv2 owner can check (python -m oracle.cv2_harness --digests) is what the oracle answers today."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_oracle_digests as mk
+    from oracle import stage_digests as sd
+    doc = sd.load()
+    assert len(doc["inputs"]) == 21
+    fresh = mk.build()
+    assert fresh["inputs"] == doc["inputs"]
+    assert doc["inputs"]["ex1.jpg"]["sgf"] == EX1_SGF
