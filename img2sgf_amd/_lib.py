@@ -86,7 +86,7 @@ assert C.sizeof(I2sResult) == 73384 + (16384 - 4096) * 13
 
 EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
            "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_jpeg_info", "i2s_detect_jpeg_batch", "i2s_jpeg_last_rounds", "i2s_jpeg_set_max_rounds", "i2s_jpeg_last_timing",
-           "i2s_classify_batch", "i2s_grid_from_lines", "i2s_find_lines",
+           "i2s_classify_batch", "i2s_grid_from_lines", "i2s_validate_grid", "i2s_find_lines",
            "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc",
            "i2s_comm_unique_id", "i2s_comm_create", "i2s_comm_destroy", "i2s_comm_last_error", "i2s_comm_shard", "i2s_comm_all",
            "i2s_set_board_sink", "i2s_allgather_boards",
@@ -139,6 +139,8 @@ class I2sLibrary:
                                          C.POINTER(I2sResult)]
         L.i2s_grid_from_lines.argtypes = [vp, u8p, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int,
                                           C.POINTER(I2sParams), C.POINTER(I2sBoard), C.POINTER(I2sResult)]
+        L.i2s_validate_grid.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, f32p, C.c_int,
+                                        C.POINTER(I2sParams), C.POINTER(I2sResult)]
         L.i2s_find_lines.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_size_t, C.POINTER(I2sParams), f32p, ip, f32p, ip]
         L.i2s_fetch_plane.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_size_t]
         L.i2s_fetch_source.argtypes = [vp, C.c_int, u8p, C.c_size_t]

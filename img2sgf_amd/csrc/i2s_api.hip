@@ -729,6 +729,42 @@ extern "C" int i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int
     return I2S_OK;
 }
 
+// validate_grid() (img2sgf.py:420-445) alone, on explicit cluster centres: what the reference's function takes -- float64 centres
+// of any spacing and order, the circle list -- and its eight outputs in `out` (valid_grid, circle_kept / n_circles_kept, vsize,
+// hsize, hcentres_complete, vcentres_complete, hspace, vspace; status says which axis failed and why).  A grid that does not
+// validate (centres closer than min_grid_spacing, a single line, too wide a gap) is an ANSWER (valid_grid = 0, all circles kept,
+// sizes 0), not an error.
+extern "C" int i2s_validate_grid(i2s_ctx* ctx, const double* hcentres, int n_h, const double* vcentres, int n_v,
+                                 const float* circles, int n_circles, const i2s_params* p, i2s_result* out)
+{
+    if (!ctx || !p || !out || n_h < 0 || n_v < 0 || n_circles < 0 || (n_h && !hcentres) || (n_v && !vcentres) || (n_circles && !circles))
+        return I2S_E_INVALID;
+    if (n_circles > I2S_MAX_CIRCLES || n_h > I2S_MAX_CENTRES || n_v > I2S_MAX_CENTRES) return I2S_E_UNSUPPORTED;
+    I2S_HIP(hipSetDevice(ctx->device));
+    Geo& g = ctx->geo;
+    g.nb = 1;
+    hipStream_t st = ctx->stream;
+    i2s_result* hr = (i2s_result*)calloc(1, sizeof(i2s_result));
+    if (!hr) return I2S_E_INVALID;
+    hr->n_circles = n_circles; hr->n_hcentres = n_h; hr->n_vcentres = n_v;
+    if (n_circles) memcpy(hr->circles, circles, (size_t)n_circles * 3 * sizeof(float));
+    if (n_h) memcpy(hr->hcentres, hcentres, (size_t)n_h * sizeof(double));
+    if (n_v) memcpy(hr->vcentres, vcentres, (size_t)n_v * sizeof(double));
+    ImgDesc& d = ctx->h_desc[0];
+    d.src = nullptr; d.w = 1; d.h = 1; d.sstride = 1; d.cn = 1; d.line_thr = 0;
+    d.gpitch = g.pitch; d.grey = plane_ptr(ctx, I2S_PLANE_GREY);
+    hipError_t e1 = hipMemcpyAsync(ctx->d_desc, ctx->h_desc, sizeof(ImgDesc), hipMemcpyHostToDevice, st);
+    hipError_t e2 = hipMemcpyAsync(ctx->d_res, hr, sizeof(i2s_result), hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(k_grid, dim3(1), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, grid_params(p), 2, ctx->d_res, ctx->d_boards);
+    hipError_t e3 = hipMemcpyAsync(out, ctx->d_res, sizeof(i2s_result), hipMemcpyDeviceToHost, st);
+    hipError_t e4 = hipStreamSynchronize(st);
+    free(hr);
+    I2S_HIP(e1); I2S_HIP(e2); I2S_HIP(e3); I2S_HIP(e4);
+    I2S_HIP(hipGetLastError());
+    ctx->last_nb = 0;                                   // no image behind this record: classify / fetch have nothing to refer to
+    return I2S_OK;
+}
+
 // find_all_lines() (img2sgf.py:258-265) on an injected `circles_removed_image_np`: the three cv.HoughLines calls of
 // find_lines (:236-244) for both directions, nothing else.
 extern "C" int i2s_find_lines(i2s_ctx* ctx, const uint8_t* image, int w, int h, size_t stride, const i2s_params* p,

@@ -118,7 +118,9 @@ __device__ __forceinline__ void cluster_axis(const float* __restrict__ rho, int 
 
 // grid (nb), block GRID_THREADS.  grey = variant plane 0.  Reads res[b].{circles, n_circles, hlines, vlines, status}
 // and fills the rest of res[b] and boards[b].  do_cluster = 0 re-runs only identify_board on the stored grid
-// (apply_black_thresh, img2sgf.py:762-766).
+// (apply_black_thresh, img2sgf.py:762-766).  do_cluster = 2 is validate_grid alone (:420-445, i2s_validate_grid): the cluster
+// centres are taken from res[b].{hcentres, vcentres} as they are -- float64, any spacing, in the given order -- and the kernel
+// stops after the radius filter (no grey plane is looked at).
 __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc, Geo g,
                                               GridParams gp, int do_cluster, i2s_result* __restrict__ res,
                                               i2s_board* __restrict__ boards)
@@ -149,8 +151,15 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
         return;
     }
     if (do_cluster) {
-        cluster_axis(R->hlines, R->n_hlines, s_sorted, gp.min_grid_spacing, s_cen[0], &s_i[0]);
-        cluster_axis(R->vlines, R->n_vlines, s_sorted, gp.min_grid_spacing, s_cen[1], &s_i[1]);
+        if (do_cluster == 2) {
+            for (int i = tid; i < R->n_hcentres; i += GRID_THREADS) s_cen[0][i] = R->hcentres[i];
+            for (int i = tid; i < R->n_vcentres; i += GRID_THREADS) s_cen[1][i] = R->vcentres[i];
+            if (tid == 0) { s_i[0] = R->n_hcentres; s_i[1] = R->n_vcentres; }
+            __syncthreads();
+        } else {
+            cluster_axis(R->hlines, R->n_hlines, s_sorted, gp.min_grid_spacing, s_cen[0], &s_i[0]);
+            cluster_axis(R->vlines, R->n_vlines, s_sorted, gp.min_grid_spacing, s_cen[1], &s_i[1]);
+        }
         if (tid == 0) {
             int status = 0;
             const int nh = s_i[0], nv = s_i[1];
@@ -215,6 +224,7 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
         __syncthreads();
         if (tid == 0) R->n_circles_kept = s_i[5];
         __syncthreads();
+        if (do_cluster == 2) return;
     }
     if (!do_cluster) {
         for (int i = tid; i < R->n_hcomplete; i += GRID_THREADS) s_cmp[0][i] = R->hcentres_complete[i];

@@ -315,6 +315,19 @@ class Detector:
         self._check(self.lib.dll.i2s_classify_batch(self._ctx, first, n, C.byref(p), boards, res))
         return [_detection_from_result(r) for r in res] if full else boards
 
+    def validate_grid_raw(self, hcentres, vcentres, circles, params: Optional[Params] = None):
+        """i2s_validate_grid: validate_grid() (img2sgf.py:420-445) on float64 centres; returns the I2sResult record."""
+        params = params or Params()
+        hc = np.ascontiguousarray(hcentres if hcentres is not None else [], np.float64).reshape(-1)
+        vc = np.ascontiguousarray(vcentres if vcentres is not None else [], np.float64).reshape(-1)
+        c = np.ascontiguousarray(circles, np.float32).reshape(-1, 3)
+        f64p, f32p = C.POINTER(C.c_double), C.POINTER(C.c_float)
+        res = I2sResult()
+        p = params.to_c()
+        self._check(self.lib.dll.i2s_validate_grid(self._ctx, hc.ctypes.data_as(f64p), len(hc), vc.ctypes.data_as(f64p), len(vc),
+                                                    c.ctypes.data_as(f32p), len(c), C.byref(p), C.byref(res)))
+        return res
+
     def grid_from_lines(self, grey, circles, hlines, vlines, params: Optional[Params] = None):
         """find_grid() (img2sgf.py:546-576) on injected circles and rho lists."""
         params = params or Params()
@@ -578,27 +591,18 @@ def cluster_lines(hlines, vlines, params: Optional[Params] = None, detector: Opt
 
 def validate_grid(hcentres, vcentres, circles, params: Optional[Params] = None, detector: Optional[Detector] = None):
     """img2sgf.py:420-445 on explicit cluster centres: (valid, newcircles, vsize, hsize, hcentres_complete,
-    vcentres_complete, hspace, vspace), or (False, circles, 0, 0, None, None, None, None).  Runs on the device: every
-    centre is handed to i2s_grid_from_lines as a pair of identical rho values (a two-member cluster whose float32 mean is the
-    centre), which requires what cluster_lines guarantees -- centres of one direction at least min_grid_spacing apart and
-    representable in float32."""
+    vcentres_complete, hspace, vspace), or (False, circles, 0, 0, None, None, None, None) -- also for centres the reference
+    would reject (closer than min_grid_spacing, a single line ...).  Takes what the reference's function takes: float64
+    centres of any spacing.  Runs on the device (i2s_validate_grid)."""
     p = params or Params()
     c = np.ascontiguousarray(circles, np.float32).reshape(-1, 3)
-
-    def doubled(x):
-        x = np.asarray(x, np.float64).reshape(-1)
-        x32 = x.astype(np.float32)
-        if not np.array_equal(x32.astype(np.float64), x):
-            raise ValueError("cluster centres must be float32 values (they are float32 means in the reference)")
-        if len(x) > 1 and np.diff(np.sort(x)).min() < p.min_grid_spacing:
-            raise ValueError("cluster centres closer than min_grid_spacing cannot come from cluster_lines")
-        return np.repeat(x32, 2)
-
     d = _detector_for([_DUMMY_GREY], detector)
-    det = d.grid_from_lines(_DUMMY_GREY, c, doubled(hcentres), doubled(vcentres), p)
-    if not det.valid_grid:
+    r = d.validate_grid_raw(hcentres, vcentres, c, p)
+    if not r.valid_grid:
         return (False, c if len(c) else [], 0, 0, None, None, None, None)
-    return (True, det.circles, det.vsize, det.hsize, det.hcentres_complete, det.vcentres_complete, det.hspace, det.vspace)
+    kept = np.frombuffer(r.circle_kept, np.uint8, count=r.n_circles).astype(bool)
+    return (True, c[kept], r.vsize, r.hsize, np.array(r.hcentres_complete[:r.n_hcomplete], np.float64),
+            np.array(r.vcentres_complete[:r.n_vcomplete], np.float64), r.hspace, r.vspace)
 
 
 def to_SGF(board, side_to_move):

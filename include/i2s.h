@@ -248,6 +248,15 @@ int  i2s_grid_from_lines(i2s_ctx* ctx, const uint8_t* grey, int w, int h,
                          const float* hlines, int n_h, const float* vlines, int n_v,
                          const i2s_params* p, i2s_board* board, i2s_result* full);
 
+/* validate_grid() (img2sgf.py:420-445) alone: the reference's arguments -- cluster centres as float64 (any spacing, any order:
+ * whatever get_cluster_centres or a caller produced), the circle list -- and its eight outputs in `out`: valid_grid, circle_kept[] /
+ * n_circles_kept (newcircles, :443), vsize, hsize, hcentres_complete, vcentres_complete, hspace, vspace.  A grid that fails
+ * (the reference returns [False, circles, 0, 0, None, None, None, None], :424/:430) comes back as valid_grid = 0, every circle
+ * kept, sizes 0 and `status` naming the axis and the reason (I2S_ST_H_TOO_CLOSE ...): an answer, never an error code.
+ * n_h, n_v <= I2S_MAX_CENTRES, n_circles <= I2S_MAX_CIRCLES (I2S_E_UNSUPPORTED beyond).  min_grid_spacing / big_space_ratio of p apply. */
+int  i2s_validate_grid(i2s_ctx* ctx, const double* hcentres, int n_h, const double* vcentres, int n_v,
+                       const float* circles, int n_circles, const i2s_params* p, i2s_result* out);
+
 /* find_all_lines() (img2sgf.py:258-265) alone: the three cv.HoughLines calls of find_lines (:236-244) for both directions
  * on an injected `circles_removed_image_np` (host, h rows of w bytes, `stride` bytes apart; any non-zero byte votes).
  * hlines / vlines: caller buffers of I2S_MAX_LINES floats, rho in find_lines' output order.  I2S_E_UNSUPPORTED if more

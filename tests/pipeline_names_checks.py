@@ -41,6 +41,34 @@ def check_validate_grid(det):
         else:
             assert out[2:] == (0, 0, None, None, None, None)
     assert n >= 10
+    # what the reference's function accepts and the round-2 detour (doubled rho values) refused: centres that are not float32
+    # values, centres closer than min_grid_spacing, unsorted / single / empty lists -- compared with the (pinned) oracle glue
+    rng = np.random.default_rng(11)
+    circ = np.array([[100.5, 100.5, 14.25], [50.5, 60.5, 3.0], [10.5, 20.5, 40.0]], np.float32)
+    cases = [([100.0, 105.0, 200.0], [50.0, 90.0, 130.0]),                       # closer than 10: (False, circles, 0, 0, None x 4)
+             ([100.1, 140.30000000000001, 180.7], [50.123456789, 90.2, 130.4]),  # not float32 values
+             ([5.0], [10.0, 50.0]), ([], [10.0, 50.0]), ([10.0, 50.0], []),
+             ([300.0, 100.0, 200.0], [10.0, 50.0, 90.0]),                         # unsorted: negative spaces -> too close
+             (list(np.arange(22) * 31.7 + 3.3), list(np.arange(21) * 29.9 + 1.1)),           # 22 and 21 lines: truncated twice
+             (list(np.arange(40) * 25.0), [10.0, 50.0, 90.0])]                    # 40 lines: valid, hsize / vsize beyond 19
+    for _ in range(40):
+        n1, n2 = int(rng.integers(2, 12)), int(rng.integers(2, 12))
+        h = np.cumsum(rng.choice([23.7, 47.4, 71.1, 9.0], n1, p=[0.6, 0.25, 0.1, 0.05])) + rng.random() * 30
+        v = np.cumsum(rng.choice([25.3, 50.6, 101.2], n2, p=[0.7, 0.2, 0.1])) + rng.random() * 30
+        cases.append((list(h), list(v)))
+    for hc, vc in cases:
+        want = glue.validate_grid(np.asarray(hc, np.float64), np.asarray(vc, np.float64), list(circ))
+        out = pipeline.validate_grid(hc, vc, circ, detector=det)
+        assert out[0] == want["valid"], (hc, vc)
+        if want["valid"]:
+            assert (out[2], out[3]) == (want["vsize"], want["hsize"])
+            np.testing.assert_array_equal(out[4], want["hc"])
+            np.testing.assert_array_equal(out[5], want["vc"])
+            assert (out[6], out[7]) == (want["hspace"], want["vspace"])
+            np.testing.assert_array_equal(np.asarray(out[1], np.float32).reshape(-1, 3), np.asarray(want["circles"], np.float32).reshape(-1, 3))
+        else:
+            assert out[2:] == (0, 0, None, None, None, None)
+            np.testing.assert_array_equal(np.asarray(out[1], np.float32).reshape(-1, 3), circ)
 
 
 def check_find_lines(det):
