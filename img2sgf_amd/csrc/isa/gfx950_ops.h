@@ -57,6 +57,10 @@ __device__ __forceinline__ void bl_bstore(BlBuf b, int row_off, unsigned off, un
 // a value the optimiser cannot see through (keeps sign-mask arithmetic from being folded back into compare + select)
 __device__ __forceinline__ int opaque_vgpr(int d) { asm("" : "+v"(d)); return d; }
 
+// v_bitop3_b32: any boolean function of three operands in one full-rate instruction.  TT = truth table with the operands
+// enumerated as a = 0xF0, b = 0xCC, c = 0xAA (e.g. a ^ b ^ c = 0x96, majority = 0xE8, a ? b : c = 0xCA).
+template <int TT> __device__ __forceinline__ unsigned bitop3(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
+
 // v_alignbyte_b32: bytes n .. n + 3 of the 8-byte value {hi:lo}
 __device__ __forceinline__ unsigned alignbyte(unsigned hi, unsigned lo, unsigned n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
 

@@ -417,22 +417,6 @@ __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ des
     }
 }
 
-// 5x5 and 7x7 together, bit-serial on bit planes.
-// The tile is transposed once into 8 bit planes (one 64-bit word per plane and row, bit i = pixel x0-4+i).  A thread owns 2
-// adjacent columns and walks down M_RPT output rows.  Per plane it keeps ONE window ring for both pixels and both medians:
-// 7 rows x 8 bits (columns c-3 .. c+4) in two dwords, one byte per row, slot = row mod 7 (static: the walk is fully
-// unrolled), so a new row costs one 64-bit shift and one byte permute per plane.  The four medians of a row differ only in
-// their candidate masks over that ring: 7x7 of the left pixel = bits 0-6 of all 7 bytes, of the right pixel bits 1-7; 5x5 =
-// the 5 middle rows, bits 1-5 / 2-6 (a popcount does not care where the bits sit).
-// The median is read off MSB first: c = candidates with bit b set; bit b of the median is 1 iff c >= need (need = rank from
-// the top still to be found among the candidates, 25 resp. 13 at the start); the candidates shrink to the matching half and,
-// for a 0 bit, need drops by c.  All bookkeeping is sign-mask arithmetic on sub / shift-right / and / xor -- the full-rate
-// instructions of this chip (profiles/r02_a_valu_rate_*.txt) -- instead of compares and selects (half rate); the only
-// half-rate instructions left in a round are the two popcounts.  Exact for any input.
-// Content adaptivity (exact, see med_repeat): bit planes that are identical to the next higher plane over the whole tile are
-// neither kept in the ring nor given a round.  Line art -- a diagram of pure black and white, a scan after the reference's
-// contrast step -- has ONE distinct plane and costs a round instead of eight; a noisy photograph has eight and costs what
-// it did (DESIGN.md quotes both).
 // ---- K4, two-valued bands: 5x5 and 7x7 medians of 0 / 255 pixels are majority votes ------------------------------------------
 // A diagram of pure black and white (the benchmark's; a scan after the reference's contrast step mostly) needs no median
 // machinery at all: with every pixel of the window 0 or 255, the 5x5 median is 255 iff at least 13 of the 25 are, the 7x7
@@ -554,31 +538,164 @@ __global__ __launch_bounds__(256) void k_median57_bin(const ImgDesc* __restrict_
     }
 }
 
-constexpr int MT_W = 56, MT_H = 72, M_RPT = 8;
+// 5x5 and 7x7 together, exact for any input, BIT-SLICED (round 3; round 2's kernel kept a pixel's window as bits of one
+// register and paid two popcounts and a dozen dependent bookkeeping instructions per pixel, window and bit plane: ~270 lane
+// instructions per pixel).  Here a register holds ONE BIT OF 32 NEIGHBOURING PIXELS and every step is a bitwise instruction
+// on all 32 at once -- v_and / v_xor / v_bitop3, the full-rate instructions of this chip (profiles/r02_a_valu_rate_*.txt).
+// The tile is transposed once into 8 bit planes (one 64-bit word per plane and row, bit i = pixel x0 - 4 + i).  A thread
+// owns 24 adjacent output pixels of one row (a 32-bit window of the row words: 24 + the aprons) and reads the median off MSB
+// first, the classic radix selection, but for 24 pixels in parallel:
+//   cand[dy][dx]  (K x K registers, bit e = element column e): is the element at offset (dy, dx) from the output pixel whose
+//                 window starts at column e - dx still a candidate, i.e. does it agree with that pixel's median in all higher bits;
+//   per plane:    t = cand & plane row (no shifts: everything is aligned on the ELEMENT's column); the K values of a column are
+//                 counted with carry-save adders (a full adder is two v_bitop3: parity and majority), the K column counts are
+//                 shifted onto the output's column and added by an adder tree -> the 6-bit number c of candidates with a 1;
+//                 the median's bit is 1 iff c > m (m = rank still to be found - 1, itself bit-sliced): the borrow of m - c;
+//                 where the bit is 0, m becomes m - c; cand &= ~(plane ^ bit).
+// 7x7: 49 + 56 + 18 + 36 + 18 + 6 + 49 instructions per plane and 24 pixels, 5x5: 25 + 30 + 12 + 24 + 15 + 4 + 25 -- 17 per
+// pixel and plane for both medians where round 2 spent 28, and full-rate ones.
+// Content adaptivity as before (exact): a plane that equals the next higher plane over the whole tile gets no round -- after the
+// upper plane's round all candidates agree in that bit, hence in this one, so the median's bit repeats.
+constexpr int MT_W = 48, MT_H = 128;                 // outputs per tile: two 24-pixel halves per row, one row per thread
 constexpr int M_ROWS = MT_H + 6, M_SSTR = 17;
 
-struct MedState { unsigned alo, ahi; int need; unsigned r; int nm; };
+// full adder / half adder on 32 bit-sliced lanes: parity and majority are one v_bitop3_b32 each
+__device__ __forceinline__ void bs_fa(unsigned a, unsigned b, unsigned c, unsigned& s, unsigned& cy) { s = bitop3<0x96>(a, b, c); cy = bitop3<0xE8>(a, b, c); }
+__device__ __forceinline__ void bs_ha(unsigned a, unsigned b, unsigned& s, unsigned& cy) { s = a ^ b; cy = a & b; }
 
-// one bit-plane round for one (pixel, window): plo / phi = the plane's ring words
-__device__ __forceinline__ void med_round(MedState& s, unsigned plo, unsigned phi)
+// K 3-bit numbers (v0 = ones, v1 = twos, v2 = fours) -> their 6-bit sum, column by column
+__device__ __forceinline__ void bs_sum7(const unsigned (&v0)[7], const unsigned (&v1)[7], const unsigned (&v2)[7], unsigned (&c)[6])
 {
-    const int c = __popc(s.alo & plo) + __popc(s.ahi & phi);
-    int d = c - s.need;
-    d = opaque_vgpr(d);                                // opaque: otherwise the compiler turns the sign mask back into compare + selects
-    const int nm = d >> 31;                            // all ones iff c < need: the median's bit is 0
-    s.alo &= plo ^ (unsigned)nm;                       // keep the candidates whose bit equals the median's
-    s.ahi &= phi ^ (unsigned)nm;
-    s.need -= c & nm;                                  // bit 0: the c candidates with a 1 are larger than the median
-    s.r = s.r + s.r - (unsigned)nm;                    // collects the COMPLEMENT of the median, MSB first
-    s.nm = nm;
+    unsigned s, t, u, k0, k1, k2, k3, k4, k5;
+    // ones: 7 bits
+    bs_fa(v0[0], v0[1], v0[2], s, k0); bs_fa(v0[3], v0[4], v0[5], t, k1); bs_fa(s, t, v0[6], c[0], k2);
+    // twos: 7 + 3
+    unsigned a0, a1, a2, b0, b1, b2, b3;
+    bs_fa(v1[0], v1[1], v1[2], a0, b0); bs_fa(v1[3], v1[4], v1[5], a1, b1); bs_fa(v1[6], k0, k1, a2, b2);
+    bs_fa(a0, a1, a2, s, b3); bs_ha(s, k2, c[1], k3);
+    // fours: 7 + 5 (b0 .. b3, k3)
+    unsigned d0, d1, d2, d3, e0, e1, e2, e3, e4;
+    bs_fa(v2[0], v2[1], v2[2], d0, e0); bs_fa(v2[3], v2[4], v2[5], d1, e1); bs_fa(v2[6], b0, b1, d2, e2); bs_fa(b2, b3, k3, d3, e3);
+    bs_fa(d0, d1, d2, s, e4); bs_ha(s, d3, c[2], k4);
+    // eights: 6 (e0 .. e4, k4)
+    unsigned f0, f1, g0, g1;
+    bs_fa(e0, e1, e2, f0, g0); bs_fa(e3, e4, k4, f1, g1); bs_ha(f0, f1, c[3], k5);
+    // sixteens: 3
+    bs_fa(g0, g1, k5, c[4], c[5]);
+    (void)t; (void)u;
+}
+__device__ __forceinline__ void bs_sum5(const unsigned (&v0)[5], const unsigned (&v1)[5], const unsigned (&v2)[5], unsigned (&c)[6])
+{
+    unsigned s, k0, k1;
+    // ones: 5
+    bs_fa(v0[0], v0[1], v0[2], s, k0); bs_fa(s, v0[3], v0[4], c[0], k1);
+    // twos: 5 + 2
+    unsigned a0, a1, b0, b1, b2;
+    bs_fa(v1[0], v1[1], v1[2], a0, b0); bs_fa(v1[3], v1[4], k0, a1, b1); bs_fa(a0, a1, k1, c[1], b2);
+    // fours: 5 + 3
+    unsigned d0, d1, e0, e1, e2, e3;
+    bs_fa(v2[0], v2[1], v2[2], d0, e0); bs_fa(v2[3], v2[4], b0, d1, e1); bs_fa(d0, d1, b1, s, e2); bs_ha(s, b2, c[2], e3);
+    // eights: 4
+    unsigned f0, g0, g1;
+    bs_fa(e0, e1, e2, f0, g0); bs_ha(f0, e3, c[3], g1);
+    // sixteens: 2 (a sum of 25 needs no bit 5)
+    c[4] = g0 ^ g1; c[5] = 0u;
 }
 
-// A plane that equals the previously processed (next higher) plane over the whole tile needs no round: after that round all
-// candidates agree in the higher bit, hence in this one; c is then |candidates| or 0, and 1 <= need <= |candidates| always
-// holds, so the median's bit repeats the previous one and neither the candidates nor `need` change.
-__device__ __forceinline__ void med_repeat(MedState& s) { s.r = s.r + s.r - (unsigned)s.nm; }
+// the K values of one element column: K one-bit inputs -> 3-bit count
+__device__ __forceinline__ void bs_col7(const unsigned (&t)[7], unsigned& o0, unsigned& o1, unsigned& o2)
+{
+    unsigned s1, c1, s2, c2, c3;
+    bs_fa(t[0], t[1], t[2], s1, c1); bs_fa(t[3], t[4], t[5], s2, c2); bs_fa(s1, s2, t[6], o0, c3); bs_fa(c1, c2, c3, o1, o2);
+}
+__device__ __forceinline__ void bs_col5(const unsigned (&t)[5], unsigned& o0, unsigned& o1, unsigned& o2)
+{
+    unsigned s1, c1, c2;
+    bs_fa(t[0], t[1], t[2], s1, c1); bs_fa(s1, t[3], t[4], o0, c2); bs_ha(c1, c2, o1, o2);
+}
 
-// One 56 x 72 tile; every thread of the workgroup calls it (it ends with a barrier, so that the LDS arrays may be reused).
+// The K x K medians of 24 pixels of tile row `row` (output row index; its window rows are plane rows row + 3 - K/2 ..), whose
+// 32-bit window of the plane row words starts at bit `sh` (0 or 24).  res[p]: bit (k - K/2) = bit p of the median of the pixel
+// at window bit k (k = 4 .. 27 are the 24 outputs).
+template <int K>
+__device__ __forceinline__ void bs_median_row(const unsigned long long* __restrict__ s_pl, int row, int sh, unsigned live, unsigned (&res)[8])
+{
+    constexpr int R = K / 2;
+    unsigned cand[K][K];
+#pragma unroll
+    for (int dy = 0; dy < K; dy++)
+#pragma unroll
+        for (int dx = 0; dx < K; dx++) cand[dy][dx] = 0xffffffffu;
+    unsigned m[6];                                     // rank still to be found, minus one, bit-sliced: starts at (K * K - 1) / 2
+#pragma unroll
+    for (int b = 0; b < 6; b++) m[b] = (((K * K - 1) / 2) >> b) & 1 ? 0xffffffffu : 0u;
+    unsigned prev = 0u;
+#pragma unroll
+    for (int p = 7; p >= 0; p--) {
+        if (!((live >> p) & 1u)) { res[p] = prev; continue; }             // block-uniform: the plane repeats its upper neighbour
+        unsigned W[K];
+#pragma unroll
+        for (int dy = 0; dy < K; dy++) {
+            const unsigned long long v = s_pl[p * M_ROWS + row + 3 - R + dy];
+            W[dy] = __builtin_amdgcn_alignbit((unsigned)(v >> 32), (unsigned)v, (unsigned)sh);
+        }
+        unsigned v0[K], v1[K], v2[K];
+#pragma unroll
+        for (int dx = 0; dx < K; dx++) {
+            unsigned t[K];
+#pragma unroll
+            for (int dy = 0; dy < K; dy++) t[dy] = p == 7 ? W[dy] : (cand[dy][dx] & W[dy]);
+            if (K == 7) bs_col7(reinterpret_cast<const unsigned (&)[7]>(t), v0[dx], v1[dx], v2[dx]);
+            else bs_col5(reinterpret_cast<const unsigned (&)[5]>(t), v0[dx], v1[dx], v2[dx]);
+            // onto the output's column: the element at offset dx of the window that starts at column a sits at column a + dx
+            if (dx) { v0[dx] >>= dx; v1[dx] >>= dx; v2[dx] >>= dx; }
+        }
+        unsigned c[6];
+        if (K == 7) bs_sum7(reinterpret_cast<const unsigned (&)[7]>(v0), reinterpret_cast<const unsigned (&)[7]>(v1), reinterpret_cast<const unsigned (&)[7]>(v2), c);
+        else bs_sum5(reinterpret_cast<const unsigned (&)[5]>(v0), reinterpret_cast<const unsigned (&)[5]>(v1), reinterpret_cast<const unsigned (&)[5]>(v2), c);
+        // m - c: the final borrow says c > m, i.e. at least `rank` candidates have a 1: the median's bit is 1
+        unsigned dif[6], bor = 0u;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            dif[b] = bitop3<0x96>(m[b], c[b], bor);
+            bor = bitop3<0x8E>(m[b], c[b], bor);                            // (~m & (c | bor)) | (c & bor)
+        }
+        const unsigned ge = bor;
+        res[p] = prev = ge;
+        if (p == 0) break;
+#pragma unroll
+        for (int b = 0; b < 6; b++) m[b] = bitop3<0xCA>(ge, m[b], dif[b]);   // ge ? m : m - c -- bit 0: the c candidates with a 1 are larger than the median
+#pragma unroll
+        for (int dx = 0; dx < K; dx++) {
+            const unsigned gsh = ge << dx;
+#pragma unroll
+            for (int dy = 0; dy < K; dy++)                                  // cand & ~(plane ^ bit); plane 7 starts from "all"
+                cand[dy][dx] = p == 7 ? ~(W[dy] ^ gsh) : bitop3<0x90>(cand[dy][dx], W[dy], gsh);
+        }
+    }
+}
+
+// 8 result planes (bit j = output pixel j, j < 24) -> 24 bytes = 6 dwords: per group of 8 pixels the plane bytes are gathered
+// into a 64-bit word (byte p = plane p) and transposed as an 8 x 8 bit matrix (byte i = pixel i)
+__device__ __forceinline__ void bs_planes_to_bytes(const unsigned (&pl)[8], unsigned (&out)[6])
+{
+#pragma unroll
+    for (int gq = 0; gq < 3; gq++) {
+        // selectors: byte gq of the low operand into byte 0 / 2, of the high operand into byte 1 / 3
+        const unsigned sel01 = (unsigned)gq | ((unsigned)(gq + 4) << 8) | 0x0c0c0000u;
+        const unsigned p01 = __builtin_amdgcn_perm(pl[1], pl[0], sel01), p23 = __builtin_amdgcn_perm(pl[3], pl[2], sel01);
+        const unsigned p45 = __builtin_amdgcn_perm(pl[5], pl[4], sel01), p67 = __builtin_amdgcn_perm(pl[7], pl[6], sel01);
+        unsigned long long x = (unsigned long long)__builtin_amdgcn_perm(p23, p01, 0x05040100u) |
+                               ((unsigned long long)__builtin_amdgcn_perm(p67, p45, 0x05040100u) << 32);
+        unsigned long long t;
+        t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x = x ^ t ^ (t << 7);
+        t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+        t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+        out[2 * gq] = (unsigned)x; out[2 * gq + 1] = (unsigned)(x >> 32);
+    }
+}
+
+// One 48 x 128 tile; every thread of the workgroup calls it (it ends with a barrier, so that the LDS arrays may be reused).
 __device__ __forceinline__ void median57_tile(const ImgDesc* __restrict__ desc, const Geo& g, uint8_t* __restrict__ out5,
                                               uint8_t* __restrict__ out7, int b, int x0, int y0, int w, int h,
                                               unsigned* __restrict__ s_src, unsigned long long* __restrict__ s_pl, unsigned& s_differs)
@@ -608,65 +725,29 @@ __device__ __forceinline__ void median57_tile(const ImgDesc* __restrict__ desc, 
         if (diff) atomicOr(&s_differs, diff);
     }
     __syncthreads();
-    // planes that get a ring and a round: plane 7 and every plane that differs from its upper neighbour (block-uniform)
+    // planes that get a round: plane 7 and every plane that differs from its upper neighbour (block-uniform)
     const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_differs | 0x80u));
-    const int cg = tid % 28, rg = tid / 28;
-    const int c = 2 * cg, r0 = rg * M_RPT;           // first tile column / output row of this thread
-    if (tid < 28 * 9 && x0 + c < w && y0 + r0 < h) {
-    const int pos = c + 1;                           // plane bit of tile column c - 3
-    unsigned rlo[8], rhi[8];                         // window ring per plane: byte k of rlo = row slot k, of rhi = slot 4 + k
+    // thread -> (half, row): the two halves of a row are 128 threads apart, so a wavefront is one half of 64 consecutive rows
+    const int half = tid >> 7, row = tid & (MT_H - 1);
+    const int xo = x0 + 24 * half, y = y0 + row;
+    if (y < h && xo < w) {
+        unsigned res[8], o7[6], o5[6];
+        bs_median_row<7>(s_pl, row, 24 * half, live, res);
 #pragma unroll
-    for (int p = 0; p < 8; p++) { rlo[p] = 0; rhi[p] = 0; }
-    uint8_t* o5 = out5 + (size_t)b * g.slot;
-    uint8_t* o7 = out7 + (size_t)b * g.slot;
+        for (int p = 0; p < 8; p++) res[p] >>= 1;                         // window bit 4 (the first output) sits at bit 4 - 3
+        bs_planes_to_bytes(res, o7);
+        bs_median_row<5>(s_pl, row, 24 * half, live, res);
 #pragma unroll
-    for (int t = 0; t < M_RPT + 6; t++) {
-        // source tile row r0 + t enters ring slot t % 7
-        constexpr unsigned SEL[4] = {0x03020104u, 0x03020400u, 0x03040100u, 0x04020100u};     // byte 0 of S0 into byte k of S1
-        const int slot = t % 7;
+        for (int p = 0; p < 8; p++) res[p] >>= 2;
+        bs_planes_to_bytes(res, o5);
+        uint8_t* p5 = out5 + (size_t)b * g.slot + rowoff(y, g.pitch) + xo;
+        uint8_t* p7 = out7 + (size_t)b * g.slot + rowoff(y, g.pitch) + xo;
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
-            if (!((live >> p) & 1u)) continue;
-            const unsigned seg = (unsigned)(s_pl[p * M_ROWS + r0 + t] >> pos);                 // byte 0 = columns c-3 .. c+4
-            if (slot < 4) rlo[p] = __builtin_amdgcn_perm(seg, rlo[p], SEL[slot]);
-            else rhi[p] = __builtin_amdgcn_perm(seg, rhi[p], SEL[slot - 4]);
-        }
-        if (t >= 6) {
-            const int y = y0 + r0 + (t - 6);
-            if (y < h) {
-                // candidate masks: 7x7 = all 7 slots; 5x5 = the 5 middle rows (not the oldest slot (t+1)%7, not the newest t%7)
-                unsigned rows5lo = 0xffffffffu, rows5hi = 0x00ffffffu;
-                {
-                    const int o = (t + 1) % 7, nw = t % 7;
-                    if (o < 4) rows5lo &= ~(0xffu << (8 * o)); else rows5hi &= ~(0xffu << (8 * (o - 4)));
-                    if (nw < 4) rows5lo &= ~(0xffu << (8 * nw)); else rows5hi &= ~(0xffu << (8 * (nw - 4)));
-                }
-                MedState m7a = {0x7f7f7f7fu, 0x007f7f7fu, 25, 0, 0}, m7b = {0xfefefefeu, 0x00fefefeu, 25, 0, 0};
-                MedState m5a = {0x3e3e3e3eu & rows5lo, 0x3e3e3e3eu & rows5hi, 13, 0, 0}, m5b = {0x7c7c7c7cu & rows5lo, 0x7c7c7c7cu & rows5hi, 13, 0, 0};
-#pragma unroll
-                for (int bit = 7; bit >= 0; bit--) {
-                    if ((live >> bit) & 1u) {
-                        med_round(m7a, rlo[bit], rhi[bit]);
-                        med_round(m7b, rlo[bit], rhi[bit]);
-                        med_round(m5a, rlo[bit], rhi[bit]);
-                        med_round(m5b, rlo[bit], rhi[bit]);
-                    } else {
-                        med_repeat(m7a); med_repeat(m7b); med_repeat(m5a); med_repeat(m5b);
-                    }
-                }
-                const unsigned v7 = ((m7a.r ^ 0xffu) & 0xffu) | (((m7b.r ^ 0xffu) & 0xffu) << 8);
-                const unsigned v5 = ((m5a.r ^ 0xffu) & 0xffu) | (((m5b.r ^ 0xffu) & 0xffu) << 8);
-                const int x = x0 + c;
-                if (x + 1 < w) {
-                    *reinterpret_cast<unsigned short*>(o5 + rowoff(y, g.pitch) + x) = (unsigned short)v5;
-                    *reinterpret_cast<unsigned short*>(o7 + rowoff(y, g.pitch) + x) = (unsigned short)v7;
-                } else {
-                    o5[rowoff(y, g.pitch) + x] = (uint8_t)v5;
-                    o7[rowoff(y, g.pitch) + x] = (uint8_t)v7;
-                }
+        for (int q = 0; q < 6; q++)
+            if (xo + 4 * q < w) {                                          // planes have a 64-byte pitch: whole dwords may be written
+                *reinterpret_cast<unsigned*>(p5 + 4 * q) = o5[q];
+                *reinterpret_cast<unsigned*>(p7 + 4 * q) = o7[q];
             }
-        }
-    }
     }
     __syncthreads();
 }

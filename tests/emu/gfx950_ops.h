@@ -21,6 +21,13 @@ static inline void bl_bstore(BlBuf b, int row_off, unsigned off, unsigned v) { m
 #define BL_CONSUME(a, b) do { } while (0)
 #define BL_SCHED_FENCE() do { } while (0)
 static inline int opaque_vgpr(int d) { return d; }
+template <int TT> static inline unsigned bitop3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r = 0;
+    for (int i = 0; i < 8; i++)          // minterm i: a = bit 2, b = bit 1, c = bit 0 of i
+        if ((TT >> i) & 1) r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);
+    return r;
+}
 static inline unsigned alignbyte(unsigned hi, unsigned lo, unsigned n) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (n & 3))); }
 static inline unsigned bytes_from_sign(unsigned t) { return ((t >> 7) & 0x01010101u) * 0xffu; }
 

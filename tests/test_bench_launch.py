@@ -53,6 +53,6 @@ def test_main_relaunches_only_without_rank_env(monkeypatch):
 def test_kernels_sha_tracks_sources():
     b = _bench()
     assert len(b.kernels_sha()) == 16
-    t, src = b.measured_traffic()
+    t, t7, src = b.measured_traffic()
     # a traffic figure is only reported for the kernels it was measured on
     assert (t is None) == (src.get("kernels_sha_of_counters") != src.get("kernels_sha_now") or src.get("file") is None)
