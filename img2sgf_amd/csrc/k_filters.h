@@ -615,10 +615,13 @@ __device__ __forceinline__ void bs_col5(const unsigned (&t)[5], unsigned& o0, un
 }
 
 // The K x K medians of 24 pixels of tile row `row` (output row index; its window rows are plane rows row + 3 - K/2 ..), whose
-// 32-bit window of the plane row words starts at bit `sh` (0 or 24).  res[p]: bit (k - K/2) = bit p of the median of the pixel
-// at window bit k (k = 4 .. 27 are the 24 outputs).
+// 32-bit window of the plane row words starts at bit `sh` (0 or 24).  One round per LIVE plane (live_list: their numbers, most
+// significant first, four bits each; a loop, not unrolled code: eight unrolled rounds of two medians are 40 KB of instructions);
+// round i leaves its result -- bit (k - K/2) = that bit of the median of the pixel at window bit k, k = 4 .. 27 -- in
+// s_res[i * 256 + thread].
 template <int K>
-__device__ __forceinline__ void bs_median_row(const unsigned long long* __restrict__ s_pl, int row, int sh, unsigned live, unsigned (&res)[8])
+__device__ __forceinline__ void bs_median_row(const unsigned long long* __restrict__ s_pl, int row, int sh, int nlive, unsigned live_list,
+                                              unsigned* __restrict__ s_res)
 {
     constexpr int R = K / 2;
     unsigned cand[K][K];
@@ -629,14 +632,14 @@ __device__ __forceinline__ void bs_median_row(const unsigned long long* __restri
     unsigned m[6];                                     // rank still to be found, minus one, bit-sliced: starts at (K * K - 1) / 2
 #pragma unroll
     for (int b = 0; b < 6; b++) m[b] = (((K * K - 1) / 2) >> b) & 1 ? 0xffffffffu : 0u;
-    unsigned prev = 0u;
-#pragma unroll
-    for (int p = 7; p >= 0; p--) {
-        if (!((live >> p) & 1u)) { res[p] = prev; continue; }             // block-uniform: the plane repeats its upper neighbour
+    const unsigned long long* rows = s_pl + row + 3 - R;
+#pragma unroll 1
+    for (int i = 0; i < nlive; i++) {
+        const int p = (int)((live_list >> (4 * i)) & 7u);                  // block-uniform
         unsigned W[K];
 #pragma unroll
         for (int dy = 0; dy < K; dy++) {
-            const unsigned long long v = s_pl[p * M_ROWS + row + 3 - R + dy];
+            const unsigned long long v = rows[p * M_ROWS + dy];
             W[dy] = __builtin_amdgcn_alignbit((unsigned)(v >> 32), (unsigned)v, (unsigned)sh);
         }
         unsigned v0[K], v1[K], v2[K];
@@ -644,7 +647,7 @@ __device__ __forceinline__ void bs_median_row(const unsigned long long* __restri
         for (int dx = 0; dx < K; dx++) {
             unsigned t[K];
 #pragma unroll
-            for (int dy = 0; dy < K; dy++) t[dy] = p == 7 ? W[dy] : (cand[dy][dx] & W[dy]);
+            for (int dy = 0; dy < K; dy++) t[dy] = cand[dy][dx] & W[dy];
             if (K == 7) bs_col7(reinterpret_cast<const unsigned (&)[7]>(t), v0[dx], v1[dx], v2[dx]);
             else bs_col5(reinterpret_cast<const unsigned (&)[5]>(t), v0[dx], v1[dx], v2[dx]);
             // onto the output's column: the element at offset dx of the window that starts at column a sits at column a + dx
@@ -661,18 +664,23 @@ __device__ __forceinline__ void bs_median_row(const unsigned long long* __restri
             bor = bitop3<0x8E>(m[b], c[b], bor);                            // (~m & (c | bor)) | (c & bor)
         }
         const unsigned ge = bor;
-        res[p] = prev = ge;
-        if (p == 0) break;
+        s_res[i * 256 + threadIdx.x] = ge;
 #pragma unroll
         for (int b = 0; b < 6; b++) m[b] = bitop3<0xCA>(ge, m[b], dif[b]);   // ge ? m : m - c -- bit 0: the c candidates with a 1 are larger than the median
 #pragma unroll
         for (int dx = 0; dx < K; dx++) {
             const unsigned gsh = ge << dx;
 #pragma unroll
-            for (int dy = 0; dy < K; dy++)                                  // cand & ~(plane ^ bit); plane 7 starts from "all"
-                cand[dy][dx] = p == 7 ? ~(W[dy] ^ gsh) : bitop3<0x90>(cand[dy][dx], W[dy], gsh);
+            for (int dy = 0; dy < K; dy++) cand[dy][dx] = bitop3<0x90>(cand[dy][dx], W[dy], gsh);      // cand & ~(plane ^ bit)
         }
     }
+}
+
+// the 8 result planes of a thread from the rounds' results: a plane without a round repeats the nearest live plane above it
+__device__ __forceinline__ void bs_collect(const unsigned* __restrict__ s_res, unsigned live, int shift, unsigned (&res)[8])
+{
+#pragma unroll
+    for (int p = 0; p < 8; p++) res[p] = s_res[(__popc(live >> p) - 1) * 256 + threadIdx.x] >> shift;
 }
 
 // 8 result planes (bit j = output pixel j, j < 24) -> 24 bytes = 6 dwords: per group of 8 pixels the plane bytes are gathered
@@ -695,79 +703,26 @@ __device__ __forceinline__ void bs_planes_to_bytes(const unsigned (&pl)[8], unsi
     }
 }
 
-// One 48 x 128 tile; every thread of the workgroup calls it (it ends with a barrier, so that the LDS arrays may be reused).
-__device__ __forceinline__ void median57_tile(const ImgDesc* __restrict__ desc, const Geo& g, uint8_t* __restrict__ out5,
-                                              uint8_t* __restrict__ out7, int b, int x0, int y0, int w, int h,
-                                              unsigned* __restrict__ s_src, unsigned long long* __restrict__ s_pl, unsigned& s_differs)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) s_differs = 0;
-    load_tile_words<M_ROWS, 16, M_SSTR, 256, BORDER_REPL>(s_src, desc[b].grey, desc[b].gpitch, w, h, x0 - 4, y0 - 3, tid);
-    __syncthreads();
-    {
-        // 8 pixels -> 8 plane bytes (8x8 bit-matrix transpose: output byte p = plane p, bit i = pixel i)
-        uint8_t* plb = reinterpret_cast<uint8_t*>(s_pl);
-        unsigned long long dacc = 0;                 // byte p: where plane p and plane p + 1 differ (over this thread's items)
-        for (int i = tid; i < M_ROWS * 8; i += 256) {
-            const int r = i >> 3, gq = i & 7;
-            unsigned long long x = (unsigned long long)s_src[r * M_SSTR + 2 * gq] | ((unsigned long long)s_src[r * M_SSTR + 2 * gq + 1] << 32);
-            unsigned long long t;
-            t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x = x ^ t ^ (t << 7);
-            t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
-            t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
-#pragma unroll
-            for (int p = 0; p < 8; p++) plb[((size_t)p * M_ROWS + r) * 8 + gq] = (uint8_t)(x >> (8 * p));
-            dacc |= x ^ (x >> 8);
-        }
-        unsigned diff = 0;
-#pragma unroll
-        for (int p = 0; p < 7; p++) diff |= ((dacc >> (8 * p)) & 0xffull) ? (1u << p) : 0u;
-        if (diff) atomicOr(&s_differs, diff);
-    }
-    __syncthreads();
-    // planes that get a round: plane 7 and every plane that differs from its upper neighbour (block-uniform)
-    const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_differs | 0x80u));
-    // thread -> (half, row): the two halves of a row are 128 threads apart, so a wavefront is one half of 64 consecutive rows
-    const int half = tid >> 7, row = tid & (MT_H - 1);
-    const int xo = x0 + 24 * half, y = y0 + row;
-    if (y < h && xo < w) {
-        unsigned res[8], o7[6], o5[6];
-        bs_median_row<7>(s_pl, row, 24 * half, live, res);
-#pragma unroll
-        for (int p = 0; p < 8; p++) res[p] >>= 1;                         // window bit 4 (the first output) sits at bit 4 - 3
-        bs_planes_to_bytes(res, o7);
-        bs_median_row<5>(s_pl, row, 24 * half, live, res);
-#pragma unroll
-        for (int p = 0; p < 8; p++) res[p] >>= 2;
-        bs_planes_to_bytes(res, o5);
-        uint8_t* p5 = out5 + (size_t)b * g.slot + rowoff(y, g.pitch) + xo;
-        uint8_t* p7 = out7 + (size_t)b * g.slot + rowoff(y, g.pitch) + xo;
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-            if (xo + 4 * q < w) {                                          // planes have a 64-byte pitch: whole dwords may be written
-                *reinterpret_cast<unsigned*>(p5 + 4 * q) = o5[q];
-                *reinterpret_cast<unsigned*>(p7 + 4 * q) = o7[q];
-            }
-    }
-    __syncthreads();
-}
-
 // The general kernel.  flags (optional): the band flags of k_median57_bin; a tile none of whose bands is flagged has exact
 // medians already.  A workgroup looks at M_TPB consecutive tiles of the (plane, row-major tile) sequence: on two-valued
 // diagrams all it does is read their flags, one tile per lane (one workgroup per tile, or one tile after the other, spent
-// 0.3 us per diagram on nothing but load latencies).
-constexpr int M_TPB = 8;
+// 0.3 us per diagram on nothing but load latencies).  The tiles it has to compute are pipelined: the source words of the next
+// one are fetched into registers while the current one is computed.
+constexpr int M_TPB = 4;
+constexpr int M_WPT = (M_ROWS * 16 + 255) / 256;     // source dwords per thread and tile
 __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
                                                   uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
                                                   const int* __restrict__ flags, int gx, int gy, int ntiles)
 {
-    __shared__ unsigned s_src[M_ROWS * M_SSTR];
+    __shared__ unsigned s_src[M_ROWS * M_SSTR];      // source tile; during the rounds: their results (256 dwords per live plane)
     __shared__ unsigned long long s_pl[8 * M_ROWS];
     __shared__ unsigned s_differs;                   // bit p: plane p differs from plane p + 1 somewhere in the tile
+    static_assert(M_ROWS * M_SSTR >= 8 * 256, "the rounds' results take the source tile's place");
     const unsigned first = tile_chunk_of_block(M_TPB, (unsigned)ntiles);
+    const int tid = threadIdx.x;
     // lane k of every wavefront looks at tile first + k (the loads of all M_TPB tiles are in flight together); the wavefronts of
     // the workgroup compute the same mask
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     bool need = false;
     if (lane < M_TPB && first + lane < (unsigned)ntiles) {
         const TileId tl = tile_of_index(first + lane, gx, gy);
@@ -788,12 +743,87 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
         }
     }
     unsigned long long todo = __ballot(need);
-    while (todo) {
-        const int k = __ffsll(todo) - 1;
-        todo &= todo - 1ull;
+    if (!todo) return;
+    // source words of a tile into registers (BORDER_REPLICATE)
+    unsigned pre[M_WPT];
+    auto fetch = [&](int k) {
+        const TileId tl = tile_of_index(first + (unsigned)k, gx, gy);
+        const ImgDesc im = desc[tl.z];
+        const int xa = tl.tx * MT_W - 4, ya = tl.ty * MT_H - 3;
+#pragma unroll
+        for (int q = 0; q < M_WPT; q++) {
+            const int i = tid + q * 256;
+            pre[q] = 0u;
+            if (i < M_ROWS * 16) pre[q] = tile_word<BORDER_REPL>(im.grey, im.gpitch, im.w, im.h, xa + 4 * (i & 15), ya + (i >> 4));
+        }
+    };
+    int k = __ffsll(todo) - 1;
+    todo &= todo - 1ull;
+    fetch(k);
+    for (;;) {
         const TileId tl = tile_of_index(first + (unsigned)k, gx, gy);
         const int b = tl.z;
-        median57_tile(desc, g, out5, out7, b, tl.tx * MT_W, tl.ty * MT_H, desc[b].w, desc[b].h, s_src, s_pl, s_differs);
+        const int w = desc[b].w, h = desc[b].h;
+        const int x0 = tl.tx * MT_W, y0 = tl.ty * MT_H;
+#pragma unroll
+        for (int q = 0; q < M_WPT; q++) {
+            const int i = tid + q * 256;
+            if (i < M_ROWS * 16) s_src[(i >> 4) * M_SSTR + (i & 15)] = pre[q];
+        }
+        if (tid == 0) s_differs = 0;
+        __syncthreads();                               // (also: everybody is done with the previous tile's planes and results)
+        const int kn = todo ? __ffsll(todo) - 1 : -1;
+        todo &= todo - 1ull;
+        if (kn >= 0) fetch(kn);                        // in flight during this tile's rounds
+        {
+            // 8 pixels -> 8 plane bytes (8x8 bit-matrix transpose: output byte p = plane p, bit i = pixel i)
+            uint8_t* plb = reinterpret_cast<uint8_t*>(s_pl);
+            unsigned long long dacc = 0;                 // byte p: where plane p and plane p + 1 differ (over this thread's items)
+            for (int i = tid; i < M_ROWS * 8; i += 256) {
+                const int r = i >> 3, gq = i & 7;
+                unsigned long long x = (unsigned long long)s_src[r * M_SSTR + 2 * gq] | ((unsigned long long)s_src[r * M_SSTR + 2 * gq + 1] << 32);
+                unsigned long long t;
+                t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x = x ^ t ^ (t << 7);
+                t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+                t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+#pragma unroll
+                for (int p = 0; p < 8; p++) plb[((size_t)p * M_ROWS + r) * 8 + gq] = (uint8_t)(x >> (8 * p));
+                dacc |= x ^ (x >> 8);
+            }
+            unsigned diff = 0;
+#pragma unroll
+            for (int p = 0; p < 7; p++) diff |= ((dacc >> (8 * p)) & 0xffull) ? (1u << p) : 0u;
+            if (diff) atomicOr(&s_differs, diff);
+        }
+        __syncthreads();
+        // planes that get a round: plane 7 and every plane that differs from its upper neighbour (block-uniform)
+        const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_differs | 0x80u));
+        unsigned live_list = 0u;
+        int nlive = 0;
+        for (int p = 7; p >= 0; p--) if ((live >> p) & 1u) { live_list |= (unsigned)p << (4 * nlive); nlive++; }
+        // thread -> (half, row): the two halves of a row are 128 threads apart, so a wavefront is one half of 64 consecutive rows
+        const int half = tid >> 7, row = tid & (MT_H - 1);
+        const int xo = x0 + 24 * half, y = y0 + row;
+        if (y < h && xo < w) {
+            unsigned res[8], o[6];
+            uint8_t* p5 = out5 + (size_t)b * g.slot + rowoff(y, g.pitch) + xo;
+            uint8_t* p7 = out7 + (size_t)b * g.slot + rowoff(y, g.pitch) + xo;
+            bs_median_row<7>(s_pl, row, 24 * half, nlive, live_list, s_src);
+            bs_collect(s_src, live, 1, res);                               // window bit 4 (the first output) sits at bit 4 - 3
+            bs_planes_to_bytes(res, o);
+#pragma unroll
+            for (int q = 0; q < 6; q++)                                    // planes have a 64-byte pitch: whole dwords may be written
+                if (xo + 4 * q < w) *reinterpret_cast<unsigned*>(p7 + 4 * q) = o[q];
+            bs_median_row<5>(s_pl, row, 24 * half, nlive, live_list, s_src);
+            bs_collect(s_src, live, 2, res);
+            bs_planes_to_bytes(res, o);
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                if (xo + 4 * q < w) *reinterpret_cast<unsigned*>(p5 + 4 * q) = o[q];
+        }
+        if (kn < 0) break;
+        k = kn;
+        __syncthreads();                               // the results (in s_src) have been read: the next tile may be stored
     }
 }
 

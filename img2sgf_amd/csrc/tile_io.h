@@ -15,6 +15,29 @@ __device__ __forceinline__ int border_idx(int p, int n)
     return iclamp(p, 0, n - 1);
 }
 
+// dword holding plane bytes (x .. x + 3, y) with border handling; x must be a multiple of 4 (it may be negative)
+template <int MODE>
+__device__ __forceinline__ unsigned tile_word(const uint8_t* __restrict__ plane, int pitch, int w, int h, int x, int y)
+{
+    if (MODE == BORDER_ONE) {
+        unsigned v1 = 0x01010101u;
+        if (y >= 0 && y < h) {
+            const uint8_t* row1 = plane + rowoff(y, pitch);
+            if (x >= 0 && x + 3 < w) v1 = *reinterpret_cast<const unsigned*>(row1 + x);
+            else {
+                v1 = 0;
+                for (int q = 0; q < 4; q++) v1 |= (unsigned)((x + q >= 0 && x + q < w) ? row1[x + q] : 1) << (8 * q);
+            }
+        }
+        return v1;
+    }
+    const int gy = border_idx<MODE>(y, h);
+    const uint8_t* row = plane + rowoff(gy, pitch);
+    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const unsigned*>(row + x);
+    return (unsigned)row[border_idx<MODE>(x, w)] | ((unsigned)row[border_idx<MODE>(x + 1, w)] << 8) |
+           ((unsigned)row[border_idx<MODE>(x + 2, w)] << 16) | ((unsigned)row[border_idx<MODE>(x + 3, w)] << 24);
+}
+
 // dst[r * DSTRIDE + c] = dword holding plane bytes (xa + 4c .. xa + 4c + 3, ya + r) with border handling.
 // xa must be a multiple of 4 (it may be negative).  All NT threads of the block call this.
 template <int ROWS, int WORDS, int DSTRIDE, int NT, int MODE>
@@ -23,31 +46,7 @@ __device__ __forceinline__ void load_tile_words(unsigned* __restrict__ dst, cons
 {
     for (int i = tid; i < ROWS * WORDS; i += NT) {
         const int r = i / WORDS, c = i - r * WORDS;
-        const int x = xa + 4 * c;
-        if (MODE == BORDER_ONE) {
-            const int gy1 = ya + r;
-            unsigned v1 = 0x01010101u;
-            if (gy1 >= 0 && gy1 < h) {
-                const uint8_t* row1 = plane + rowoff(gy1, pitch);
-                if (x >= 0 && x + 3 < w) v1 = *reinterpret_cast<const unsigned*>(row1 + x);
-                else {
-                    v1 = 0;
-                    for (int q = 0; q < 4; q++) v1 |= (unsigned)((x + q >= 0 && x + q < w) ? row1[x + q] : 1) << (8 * q);
-                }
-            }
-            dst[r * DSTRIDE + c] = v1;
-            continue;
-        }
-        const int gy = border_idx<MODE>(ya + r, h);
-        const uint8_t* row = plane + rowoff(gy, pitch);
-        unsigned v;
-        if (x >= 0 && x + 3 < w) {
-            v = *reinterpret_cast<const unsigned*>(row + x);
-        } else {
-            v = (unsigned)row[border_idx<MODE>(x, w)] | ((unsigned)row[border_idx<MODE>(x + 1, w)] << 8) |
-                ((unsigned)row[border_idx<MODE>(x + 2, w)] << 16) | ((unsigned)row[border_idx<MODE>(x + 3, w)] << 24);
-        }
-        dst[r * DSTRIDE + c] = v;
+        dst[r * DSTRIDE + c] = tile_word<MODE>(plane, pitch, w, h, xa + 4 * c, ya + r);
     }
 }
 
