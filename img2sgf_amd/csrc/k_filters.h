@@ -198,6 +198,9 @@ __device__ __forceinline__ void bl_median_pixels(unsigned L, unsigned M, unsigne
 #ifndef BL_WAVES
 #define BL_WAVES 3
 #endif
+#ifndef BL_PREFETCH2
+#define BL_PREFETCH2 1
+#endif
 __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
                                                  uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
                                                  BlurTaps tps, int gx, int gy)
@@ -280,6 +283,15 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
         nM = bl_bload(sbuf, ro, xm);
         nE = bl_bload(sbuf, ro, xe);
     }
+#if BL_PREFETCH2
+    unsigned n2M, n2E;                       // a second row in flight
+    {
+        ry.step();
+        const int ro = rowoff(ry.y, sp);
+        n2M = bl_bload(sbuf, ro, xm);
+        n2E = bl_bload(sbuf, ro, xe);
+    }
+#endif
     static_assert((BL_R + 6) % 7 == 0, "the row loop is unrolled by the ring depth");
     const int t_end = imin(BL_R + 6, h + 3 - (y0 - 3));               // input rows beyond h + 2 feed no output of this band
     const BlBuf o_m = bl_buf(med3 + obase), o_3 = bl_buf(out3 + obase), o_5 = bl_buf(out5 + obase), o_7 = bl_buf(out7 + obase);
@@ -289,12 +301,22 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
             const int t = t0 + u;
             const int yi = y0 - 3 + t;
             const unsigned M = nM, E = nE;
+#if BL_PREFETCH2
+            nM = n2M; nE = n2E;
+            {
+                ry.step();
+                const int ro = rowoff(ry.y, sp);
+                n2M = bl_bload(sbuf, ro, xm);
+                n2E = bl_bload(sbuf, ro, xe);
+            }
+#else
             {
                 ry.step();
                 const int ro = rowoff(ry.y, sp);
                 nM = bl_bload(sbuf, ro, xm);
                 nE = bl_bload(sbuf, ro, xe);
             }
+#endif
             const unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E);
             unsigned gl = L, gm = M, gr = R;
             if (fix) {
@@ -710,7 +732,10 @@ __device__ __forceinline__ void bs_planes_to_bytes(const unsigned (&pl)[8], unsi
 // one are fetched into registers while the current one is computed.
 constexpr int M_TPB = 4;
 constexpr int M_WPT = (M_ROWS * 16 + 255) / 256;     // source dwords per thread and tile
-__global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
+#ifndef M_WAVES
+#define M_WAVES 3
+#endif
+__global__ __launch_bounds__(256, M_WAVES) void k_median57(const ImgDesc* __restrict__ desc, Geo g,
                                                   uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
                                                   const int* __restrict__ flags, int gx, int gy, int ntiles)
 {
@@ -750,6 +775,17 @@ __global__ __launch_bounds__(256) void k_median57(const ImgDesc* __restrict__ de
         const TileId tl = tile_of_index(first + (unsigned)k, gx, gy);
         const ImgDesc im = desc[tl.z];
         const int xa = tl.tx * MT_W - 4, ya = tl.ty * MT_H - 3;
+        if (xa >= 0 && ya >= 0 && xa + 64 <= im.w && ya + M_ROWS <= im.h) {
+            // the tile and its apron lie inside the image (block-uniform): plain dword loads, no border arithmetic
+            const uint8_t* base = im.grey + rowoff(ya, im.gpitch) + xa + 4 * (tid & 15);
+#pragma unroll
+            for (int q = 0; q < M_WPT; q++) {
+                const int i = tid + q * 256;
+                pre[q] = 0u;
+                if (i < M_ROWS * 16) pre[q] = *reinterpret_cast<const unsigned*>(base + rowoff(i >> 4, im.gpitch));
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < M_WPT; q++) {
             const int i = tid + q * 256;
