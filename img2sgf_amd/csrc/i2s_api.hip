@@ -464,11 +464,11 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_SEG(4);
         const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
         if (fused0)
-            hipLaunchKernelGGL(k_sobel_nms_rows, dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
-                               p->hc_param1, p->canny_hi, 2, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
+            hipLaunchKernelGGL((k_sobel_nms_rows<2>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
+                               p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
         else if (has_c1)
-            hipLaunchKernelGGL(k_sobel_nms_rows, dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
-                               p->canny_lo, p->canny_hi, p->canny_hi, 1, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
+            hipLaunchKernelGGL((k_sobel_nms_rows<1>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
+                               p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
         if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
         I2S_SEG(5);
         rc = run_hysteresis(ctx, 0, fx * fy * nb);
@@ -476,8 +476,8 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
         I2S_SEG(6);
         const int v_first = fused0 ? 1 : 0;
-        hipLaunchKernelGGL(k_sobel_nms_rows, dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, 0, st, ctx->d_desc, g, grey, map0,
-                           (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, 0, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
+        hipLaunchKernelGGL((k_sobel_nms_rows<0>), dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, 0, st, ctx->d_desc, g, grey, map0,
+                           (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
         I2S_SEG(7);
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;

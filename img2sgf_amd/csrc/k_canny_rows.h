@@ -18,18 +18,18 @@ constexpr int CR_R = CT_H;       // output rows per wavefront = one row of hyste
 
 struct CrThr { unsigned lowp, highp, high0p; };
 
-// suppression of one pixel pair (two 16-bit lanes): cur = magnitudes, L / R / above / below and the four diagonals, gx / gy the
-// gradients.  Returns the map values (0 / 1 / 2 per 16-bit lane) for the thresholds (low, high) and (low, high0).
+// suppression of one pixel pair (two 16-bit lanes): cur = magnitudes, L / R / above / below and the four diagonals, ax / ay the
+// absolute gradients, msk = 0xffff where the gradient signs differ.  Returns the map values (0 / 1 / 2 per 16-bit lane) for the
+// thresholds (low, high) and -- TWO -- (low, high0).
+template <bool TWO>
 __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned r1, unsigned c0, unsigned c2, unsigned l0, unsigned r0,
-                                            unsigned l2, unsigned r2, unsigned gxp, unsigned gyp, const CrThr& th, unsigned& o, unsigned& om)
+                                            unsigned l2, unsigned r2, unsigned axp, unsigned ay, unsigned msk, const CrThr& th, unsigned& o, unsigned& om)
 {
     // The two neighbours of the pixel's sector are selected first and compared once: horizontal (left, right), vertical
     // (above, below), diagonal by the gradient signs -- signs differ -> (above right, below left), else (above left, below
     // right).  OpenCV keeps cur > first && cur >= second on the axes and cur > both on a diagonal; cur > d  <=>  cur >= d + 1.
-    const unsigned msk = pk_bits(pk_from(gxp ^ gyp) >> 15);
     const unsigned d1 = bsel(msk, r0, l0), d2 = pk_bits(pk_from(bsel(msk, l2, r2)) + (short)1);
-    const v2u ax = pku_from(pk_bits(pk_abs(pk_from(gxp))));
-    const unsigned ay = pk_bits(pk_abs(pk_from(gyp)));
+    const v2u ax = pku_from(axp);
     // |dy| 2^15 < |dx| 13573  <=>  |dy| <= q,  |dy| 2^15 > |dx| 79109  <=>  |dy| > 2 |dx| + q,  q = floor(|dx| 13573 / 2^15) = (|dx| 53 + (|dx| 5 >> 8)) >> 7:
     // 13573 = 53 * 256 + 5 is odd, so the quotient is never exact for |dx| > 0, and for |dx| = |dy| = 0 the magnitude is 0 and nothing is kept
     const v2u q = (ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7;
@@ -39,15 +39,16 @@ __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned 
     const unsigned keep = pk_gt(cur, n1) & ~pk_gt(n2, cur);
     const unsigned kept = keep & pk_gt(cur, th.lowp);
     o = (kept & pk_gt(cur, th.highp) & 0x00020002u) | (~kept & 0x00010001u);
-    om = (kept & pk_gt(cur, th.high0p) & 0x00020002u) | (~kept & 0x00010001u);
+    if (TWO) om = (kept & pk_gt(cur, th.high0p) & 0x00020002u) | (~kept & 0x00010001u);
 }
 
 // main_mode: 0 = HoughCircles' Canny of variants v_first .. (plane v -> map 1 + v), 1 = main Canny of grey
 // sources (plane 0 -> map 0 + edge image, threshold high_main), 2 = both at once for the grey plane.
 // grid: ceil(w / 1024) x ceil(h / CR_R) x (nb * variants) workgroups of 4 wavefronts (4 consecutive 256-pixel column groups).
+template <int main_mode>
 __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
                                                         uint8_t* __restrict__ maps, uint8_t* __restrict__ edges, int v_first, int low,
-                                                        int high, int high_main, int main_mode, int* __restrict__ weak,
+                                                        int high, int high_main, int* __restrict__ weak,
                                                         int* __restrict__ weak_main, int gx, int gy)
 {
     const TileId tl = tile_of_block(gx, gy);
@@ -108,12 +109,15 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     const unsigned xm = active ? (unsigned)x0 : 0u, xeo = has_e ? (unsigned)(lane == 0 ? x0 - 4 : x0 + 4) : 0u;
 
     unsigned PA[3], PB[3], PC[3], PE[3];            // pixel pairs (-1,0), (1,2), (3,4) and the end-lane bytes of the last 3 input rows
-    unsigned M01[3], M23[3], ML[3], MR[3];          // magnitudes of the last 3 gradient rows: own pairs, left pair of lane - 1, right pair of lane + 1
-    unsigned GX01[2], GX23[2], GY01[2], GY23[2];    // gradients of the last 2 gradient rows
+    // magnitudes of the last 3 gradient rows: the own pairs (pixels 0,1 and 2,3) and the same row shifted by one pixel --
+    // (-1,0), (1,2), (3,4), formed ONCE per row from the neighbour lanes' pairs (each row is used by three suppressions)
+    unsigned M01[3], M23[3], SL[3], SM[3], SR[3];
+    // of the last 2 gradient rows: |dx|, |dy| and the mask "signs differ" (the suppression needs nothing else of the gradients)
+    unsigned AX01[2], AX23[2], AY01[2], AY23[2], SG01[2], SG23[2];
 #pragma unroll
-    for (int i = 0; i < 3; i++) { PA[i] = PB[i] = PC[i] = PE[i] = 0; M01[i] = M23[i] = ML[i] = MR[i] = 0; }
+    for (int i = 0; i < 3; i++) { PA[i] = PB[i] = PC[i] = PE[i] = 0; M01[i] = M23[i] = SL[i] = SM[i] = SR[i] = 0; }
 #pragma unroll
-    for (int i = 0; i < 2; i++) { GX01[i] = GX23[i] = GY01[i] = GY23[i] = 0; }
+    for (int i = 0; i < 2; i++) { AX01[i] = AX23[i] = AY01[i] = AY23[i] = SG01[i] = SG23[i] = 0; }
 
     unsigned nM, nE;
     {
@@ -168,8 +172,12 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                     const unsigned r01 = k01 & rowm, r23 = k23 & rowm;
                     dx01 = pk_bits(x01) & r01; dy01 = pk_bits(y01) & r01;
                     dx23 = pk_bits(x23) & r23; dy23 = pk_bits(y23) & r23;
-                    mg01 = pk_bits(pk_abs(pk_from(dx01)) + pk_abs(pk_from(dy01)));
-                    mg23 = pk_bits(pk_abs(pk_from(dx23)) + pk_abs(pk_from(dy23)));
+                    const unsigned ax01 = pk_bits(pk_abs(pk_from(dx01))), ay01 = pk_bits(pk_abs(pk_from(dy01)));
+                    const unsigned ax23 = pk_bits(pk_abs(pk_from(dx23))), ay23 = pk_bits(pk_abs(pk_from(dy23)));
+                    mg01 = pk_bits(pk_from(ax01) + pk_from(ay01));
+                    mg23 = pk_bits(pk_from(ax23) + pk_from(ay23));
+                    AX01[g2] = ax01; AX23[g2] = ax23; AY01[g2] = ay01; AY23[g2] = ay23;
+                    SG01[g2] = pk_bits(pk_from(dx01 ^ dy01) >> 15); SG23[g2] = pk_bits(pk_from(dx23 ^ dy23) >> 15);
                     // end lanes: magnitude at column xe from bytes (xe - 1, xe, xe + 1) of the three rows
                     const unsigned et = PE[top], em = PE[mid], eb = PE[bot];
                     const int sc = (int)__builtin_amdgcn_udot4(et, 0x00010000u, __builtin_amdgcn_udot4(em, 0x00020000u, __builtin_amdgcn_udot4(eb, 0x00010000u, 0u, false), false), false);
@@ -177,11 +185,12 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                     const int edy = (int)__builtin_amdgcn_udot4(eb, 0x00010201u, 0u, false) - (int)__builtin_amdgcn_udot4(et, 0x00010201u, 0u, false);
                     mge = e_ok ? (unsigned)(iabs_(sc - sa) + iabs_(edy)) & rowm : 0u;
                 }
-                GX01[g2] = dx01; GX23[g2] = dx23; GY01[g2] = dy01; GY23[g2] = dy23;
                 M01[gs] = mg01; M23[gs] = mg23;
                 // pair (x0 - 2, x0 - 1) of the left neighbour and pair (x0 + 4, x0 + 5) of the right one (only their inner halves are used)
-                ML[gs] = bl_from_prev_lane(mg23, mge << 16);
-                MR[gs] = bl_from_next_lane(mg01, mge);
+                const unsigned ml = bl_from_prev_lane(mg23, mge << 16), mr = bl_from_next_lane(mg01, mge);
+                SL[gs] = __builtin_amdgcn_alignbit(mg01, ml, 16);
+                SM[gs] = __builtin_amdgcn_alignbit(mg23, mg01, 16);
+                SR[gs] = __builtin_amdgcn_alignbit(mr, mg23, 16);
             }
             // suppression of row yn = yg - 1 (magnitude rows yn - 1, yn, yn + 1 = slots gs + 1, gs + 2, gs; gradients in slot g2 ^ 1)
             const int yn = yi - 2;
@@ -192,26 +201,19 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                 const unsigned mb01 = M01[rc], mb23 = M23[rc];
                 const int mxall = imax(imax((int)(mb01 & 0xffffu), (int)(mb01 >> 16)), imax((int)(mb23 & 0xffffu), (int)(mb23 >> 16)));
                 if (__any(mxall > low ? 1 : 0)) {
-                    unsigned Lr[3][2], Cr[3][2], Rr[3][2];
-                    const int rows[3] = {ra, rc, rb};
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++) {
-                        const unsigned a = ML[rows[rr]], b0 = M01[rows[rr]], b1 = M23[rows[rr]], c = MR[rows[rr]];
-                        Cr[rr][0] = b0; Cr[rr][1] = b1;
-                        Lr[rr][0] = __builtin_amdgcn_alignbit(b0, a, 16);
-                        Rr[rr][0] = Lr[rr][1] = __builtin_amdgcn_alignbit(b1, b0, 16);
-                        Rr[rr][1] = __builtin_amdgcn_alignbit(c, b1, 16);
-                    }
-                    unsigned o0, o0m, o1, o1m;
-                    cr_nms_pair(Cr[1][0], Lr[1][0], Rr[1][0], Cr[0][0], Cr[2][0], Lr[0][0], Rr[0][0], Lr[2][0], Rr[2][0], GX01[gq], GY01[gq], th, o0, o0m);
-                    cr_nms_pair(Cr[1][1], Lr[1][1], Rr[1][1], Cr[0][1], Cr[2][1], Lr[0][1], Rr[0][1], Lr[2][1], Rr[2][1], GX23[gq], GY23[gq], th, o1, o1m);
+                    unsigned o0, o0m = 0, o1, o1m = 0;
+                    constexpr bool TWO = main_mode == 2;
+                    cr_nms_pair<TWO>(M01[rc], SL[rc], SM[rc], M01[ra], M01[rb], SL[ra], SM[ra], SL[rb], SM[rb], AX01[gq], AY01[gq], SG01[gq], th, o0, o0m);
+                    cr_nms_pair<TWO>(M23[rc], SM[rc], SR[rc], M23[ra], M23[rb], SM[ra], SR[ra], SM[rb], SR[rb], AX23[gq], AY23[gq], SG23[gq], th, o1, o1m);
                     outw = __builtin_amdgcn_perm(o1, o0, 0x06040200u);
-                    outw0 = __builtin_amdgcn_perm(o1m, o0m, 0x06040200u);
+                    if (TWO) outw0 = __builtin_amdgcn_perm(o1m, o0m, 0x06040200u);
                 }
                 outw = (outw & vm) | (0x01010101u & ~vm);
-                outw0 = (outw0 & vm) | (0x01010101u & ~vm);
                 wk_acc |= (outw - 0x01010101u) & ~outw & 0x80808080u;            // some byte == 0
-                wk0_acc |= (outw0 - 0x01010101u) & ~outw0 & 0x80808080u;
+                if (main_mode == 2) {
+                    outw0 = (outw0 & vm) | (0x01010101u & ~vm);
+                    wk0_acc |= (outw0 - 0x01010101u) & ~outw0 & 0x80808080u;
+                }
             }
             // stores after the wait for the prefetched row (see BL_CONSUME in k_filters.h)
             BL_SCHED_FENCE();
