@@ -55,7 +55,7 @@ def cpu_baseline(per_worker):
 
 
 # the sources of the blur+Canny stage's kernels (and what they include)
-STAGE_SOURCES = ("i2s_types.h", "k_canny.h", "k_canny_rows.h", "k_filters.h", "tile_io.h")
+STAGE_SOURCES = ("i2s_types.h", "k_canny.h", "k_canny_rows.h", "k_filters.h", "tile_io.h", "isa/gfx950_ops.h")
 
 
 def kernels_sha():

@@ -46,8 +46,8 @@ struct i2s_ctx {
     size_t src_slot = 0;
     ImgDesc* d_desc = nullptr;
     ImgDesc* h_desc = nullptr;
-    int* d_flags = nullptr;      // [2][HYST_MAX_PASSES]
-    int* h_flags = nullptr;      // [2] last-pass flags
+    int* d_flags = nullptr;      // [2][HYST_MAX_PASSES] "pass p changed something" per phase | [2] grid-barrier counters | [2] passes used (k_hysteresis_tail)
+    int* h_flags = nullptr;      // [2] passes each phase needed (-1: not converged)
     unsigned* d_cent_list = nullptr;
     int* d_counts = nullptr;     // cent_count | est_count | vcount | overflow
     unsigned long long* d_est_keys = nullptr;
@@ -89,7 +89,7 @@ struct i2s_ctx {
     i2s_board* d_sink = nullptr;    // i2s_set_board_sink: device array that also receives image i's record at [i]
     int* d_dbg_acc = nullptr;
     int debug = 0;
-    int hyst_passes = 6;
+    int hyst_k[2] = {1, 1};         // plain hysteresis launches per phase in front of the persistent tail: what the last call needed
     int last_nb = 0;
     HoughTrig last_trig{};
     float timing[5] = {0, 0, 0, 0, 0};
@@ -221,7 +221,7 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipHostMalloc(&ctx->h_jstatus, nb * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_jflag, sizeof(uint32_t)));
     I2S_HIP(hipMalloc(&ctx->d_jstatus, nb * sizeof(int)));
-    I2S_HIP(hipMalloc(&ctx->d_flags, 2 * HYST_MAX_PASSES * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_flags, (2 * HYST_MAX_PASSES + 4) * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_flags, 2 * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * g.cent_cap * sizeof(unsigned)));
     I2S_HIP(hipMalloc(&ctx->d_counts, counts_bytes(ctx)));
@@ -340,14 +340,24 @@ static GridParams grid_params(const i2s_params* p)
 
 static inline int* worklist(i2s_ctx* ctx, int phase) { return ctx->d_weak + (size_t)phase * ((size_t)ctx->max_batch * NMAP * ctx->geo.tiles + 1); }
 
+// One phase of hysteresis (0: the main Canny's map, 1: HoughCircles' maps): hyst_k[phase] plain launches -- as many passes as the
+// previous call needed -- and ONE persistent launch behind them that runs whatever is still necessary with grid-wide barriers and
+// reports the number of passes the phase took (k_canny.h).  On diagrams that is 1 + 1 launches per phase.
 static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
 {
     int* flags = ctx->d_flags + (size_t)phase * HYST_MAX_PASSES;
+    int* counter = ctx->d_flags + 2 * HYST_MAX_PASSES + phase;
+    int* info = ctx->d_flags + 2 * HYST_MAX_PASSES + 2 + phase;
     const int nblocks = max_tiles < HY_BLOCKS ? max_tiles : HY_BLOCKS;      // the worklist cannot be longer than max_tiles
-    for (int pass = 0; pass < ctx->hyst_passes; pass++)
-        hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, plane_ptr(ctx, I2S_PLANE_CANNY_MAP),
-                           phase == 0 ? plane_ptr(ctx, I2S_PLANE_EDGES) : (uint8_t*)nullptr, flags, pass, worklist(ctx, phase), ctx->d_chg);
-    I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], flags + ctx->hyst_passes - 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    uint8_t* maps = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
+    uint8_t* edges = phase == 0 ? plane_ptr(ctx, I2S_PLANE_EDGES) : (uint8_t*)nullptr;
+    const int k = ctx->hyst_k[phase];
+    for (int pass = 0; pass < k; pass++)
+        hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, pass,
+                           worklist(ctx, phase), ctx->d_chg);
+    hipLaunchKernelGGL(k_hysteresis_tail, dim3(HY_TAIL_BLOCKS), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, k,
+                       HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, counter, info);
+    I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
 
@@ -417,7 +427,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     for (;;) {
         I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
         I2S_HIP(hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx), st));
-        I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, 2 * HYST_MAX_PASSES * sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, (2 * HYST_MAX_PASSES + 4) * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 0), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 1), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_chg, 0, (size_t)ctx->max_batch * NMAP * g.tiles * sizeof(int), st));
@@ -531,13 +541,20 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             I2S_HIP(hipMemcpyAsync(full + dst[i], ctx->d_res + i, sizeof(i2s_result), hipMemcpyDeviceToHost, st));
         I2S_HIP(hipStreamSynchronize(st));
         I2S_HIP(hipGetLastError());
-        if (ctx->h_flags[0] == 0 && ctx->h_flags[1] == 0) break;
-        // hysteresis had not reached its fixed point within the pass budget: redo this pass with more passes
-        if (ctx->hyst_passes >= HYST_MAX_PASSES) {
-            snprintf(ctx->err, sizeof(ctx->err), "Canny hysteresis did not converge in %d passes", HYST_MAX_PASSES);
-            return I2S_E_HIP;
+        bool converged = true;
+        for (int ph = 0; ph < 2; ph++) {
+            const int used = ctx->h_flags[ph];                              // passes the phase needed, -1: budget or barrier timeout
+            if (used < 0) {
+                converged = false;
+                if (ctx->hyst_k[ph] >= HYST_MAX_PASSES) {
+                    snprintf(ctx->err, sizeof(ctx->err), "Canny hysteresis did not converge in %d passes", HYST_MAX_PASSES);
+                    return I2S_E_HIP;
+                }
+                ctx->hyst_k[ph] = ctx->hyst_k[ph] * 2 + 6 < HYST_MAX_PASSES ? ctx->hyst_k[ph] * 2 + 6 : HYST_MAX_PASSES;
+            } else ctx->hyst_k[ph] = used < 1 ? 1 : (used > 64 ? 64 : used);
         }
-        ctx->hyst_passes = ctx->hyst_passes * 2 < HYST_MAX_PASSES ? ctx->hyst_passes * 2 : HYST_MAX_PASSES;
+        if (converged) break;
+        // hysteresis had not reached its fixed point: redo this device pass with more plain launches
     }
     for (int i = 0; i < nb; i++) boards[dst[i]] = ctx->h_boards[i];
     float ms;

@@ -68,4 +68,34 @@ __device__ __forceinline__ unsigned alignbyte(unsigned hi, unsigned lo, unsigned
 // with hi = t << 8 those are bytes 1, 3 (lo) and 0, 2 (hi) of t.
 __device__ __forceinline__ unsigned bytes_from_sign(unsigned t) { return __builtin_amdgcn_perm(t << 8, t, 0x090b080au); }
 
+// ---- grid-wide barrier of a small persistent grid (k_hysteresis_tail) ----------------------------------------------------------
+// HY_TAIL_BLOCKS workgroups of 256 threads -- one per CU, an eighth of what the chip keeps resident, so every workgroup of the grid
+// is running whatever else shares the GPU.  One monotonic counter in global memory; barrier number n is passed when it reaches
+// (n + 1) * gridDim.x.  Per MI355X_MICROARCH.md (inter-workgroup visibility): lane 0 releases at agent scope BEFORE it arrives (its
+// workgroup's stores, behind the __syncthreads, become visible in L2 / memory), polls with relaxed agent-scope loads, acquires at agent
+// scope AFTER (the CU's vector L1 is invalidated), and the inline s_waitcnt keeps the compiler from dropping the wait behind the
+// release.  Every spin is bounded: on a timeout the caller gives up and the host falls back to plain launches.
+constexpr int HY_TAIL_BLOCKS = 256;
+__device__ __forceinline__ bool grid_barrier(int* counter, int& target, int* s_ok)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        target += (int)gridDim.x;
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        for (long spins = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
+            __builtin_amdgcn_s_sleep(8);
+            if (spins > (1l << 22)) { ok = 0; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+// a value another workgroup wrote before the last grid barrier
+__device__ __forceinline__ int load_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 }  // namespace i2s

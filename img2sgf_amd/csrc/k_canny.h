@@ -5,6 +5,7 @@
 #pragma once
 #include "i2s_types.h"
 #include "tile_io.h"
+#include <gfx950_ops.h>
 
 namespace i2s {
 
@@ -145,12 +146,11 @@ __device__ __forceinline__ unsigned hy_bits8(unsigned f_lo, unsigned f_hi)
 // flood the seeds S along the runs of M (S subset of M) towards higher bits
 __device__ __forceinline__ unsigned long long hy_fill_up(unsigned long long S, unsigned long long M) { return (((M + S) ^ M) & M) | S; }
 
-__global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
-                                                    uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
-                                                    const int* __restrict__ wl, int* __restrict__ chg)
+// one pass over this workgroup's share of the worklist (entries first, first + stride, ...; one wavefront per entry)
+__device__ __forceinline__ void hysteresis_pass(const ImgDesc* __restrict__ desc, const Geo& g, uint8_t* __restrict__ maps,
+                                                uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
+                                                const int* __restrict__ wl, int* __restrict__ chg)
 {
-    static_assert(CT_W == 64 && CT_H + 2 <= 64, "one 64-bit mask per row, one lane per row incl. the apron");
-    if (pass > 0 && flags[pass - 1] == 0) return;
     const int nwl = wl[0];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int e = blockIdx.x * 4 + wave; e < nwl; e += gridDim.x * 4) {
@@ -245,6 +245,46 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
             }
         }
         if (lane == 0) { flags[pass] = 1; chg[tbase + tile] = pass + 1; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
+                                                    uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
+                                                    const int* __restrict__ wl, int* __restrict__ chg)
+{
+    static_assert(CT_W == 64 && CT_H + 2 <= 64, "one 64-bit mask per row, one lane per row incl. the apron");
+    if (pass > 0 && flags[pass - 1] == 0) return;
+    hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg);
+}
+
+// The tail of a phase: ONE launch behind the `first_pass` plain launches (a number the host adapts to what the previous calls
+// needed), which runs whatever passes are still necessary inside the kernel -- a grid of HY_TAIL_BLOCKS workgroups with a grid-wide
+// barrier between passes -- and reports how many passes the phase took: info[0] = passes that ran until one changed nothing
+// (first_pass if the plain launches had already converged), or -1 when the budget `max_pass` or a barrier timeout was hit (the
+// host then redoes the device pass with plain launches).  On diagrams the tail finds flags[first_pass - 1] == 0 and returns at
+// once: a phase costs first_pass + 1 launches instead of a fixed budget of six.
+__global__ __launch_bounds__(256) void k_hysteresis_tail(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
+                                                         uint8_t* __restrict__ edges, int* __restrict__ flags, int first_pass, int max_pass,
+                                                         const int* __restrict__ wl, int* __restrict__ chg, int* __restrict__ counter,
+                                                         int* __restrict__ info)
+{
+    __shared__ int s_ok;
+    int target = 0;
+    int pass = first_pass;
+    bool ok = true;
+    for (; pass < max_pass; pass++) {
+        if (load_agent(&flags[pass - 1]) == 0) break;                    // the previous pass changed nothing: fixed point
+        hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg);
+        ok = grid_barrier(counter, target, &s_ok);
+        if (!ok) break;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int used = -1;
+        if (ok && pass < max_pass) {
+            used = pass;                                                   // flags[pass - 1] == 0
+            for (int q = 0; q < pass; q++) if (load_agent(&flags[q]) == 0) { used = q + 1; break; }
+        }
+        info[0] = used;
     }
 }
 

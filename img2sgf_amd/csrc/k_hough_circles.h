@@ -517,6 +517,11 @@ __global__ __launch_bounds__(1024) void k_circles_final(Geo g, const unsigned lo
                                                        float min_dist, int min_r,
                                                        float* __restrict__ vcirc, int* __restrict__ vcount, int* __restrict__ overflow)
 {
+    // gfx950 only: the large-capacity instantiation (ECAP = 16384: 128 KB of keys + 16 KB of status bytes) needs the 160 KB of LDS a
+    // CDNA4 CU has, runs one workgroup per CU and keeps the all-pairs sweep (no LDS left for the neighbour grid): contexts of more
+    // than one megapixel trade speed on crowded images for capacity.
+    static_assert(sizeof(unsigned long long) * ECAP + sizeof(short) * VCAP + (HASH ? 4 * FIN_BUCKETS + 2 * ECAP : 6) + 128 <= 160 * 1024,
+                  "k_circles_final: LDS arrays exceed a gfx950 CU's 160 KB");
     __shared__ unsigned long long s_key[ECAP];
     __shared__ short s_kx[VCAP];
     __shared__ int s_wsum[FIN_THREADS / 64];

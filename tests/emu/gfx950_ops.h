@@ -31,4 +31,10 @@ template <int TT> static inline unsigned bitop3(unsigned a, unsigned b, unsigned
 static inline unsigned alignbyte(unsigned hi, unsigned lo, unsigned n) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (n & 3))); }
 static inline unsigned bytes_from_sign(unsigned t) { return ((t >> 7) & 0x01010101u) * 0xffu; }
 
+// the emulator runs the workgroups of a grid one after the other: the persistent tail kernel is launched with ONE workgroup, for
+// which the grid barrier is a workgroup barrier
+constexpr int HY_TAIL_BLOCKS = 1;
+static inline bool grid_barrier(int* counter, int& target, int* s_ok) { (void)counter; (void)target; (void)s_ok; __syncthreads(); return true; }
+static inline int load_agent(const int* p) { return *p; }
+
 }  // namespace i2s

@@ -285,3 +285,21 @@ def test_blur_bank_shapes_emulated(lib):
     det.detect_batch([np.full((20, 40), 255, np.uint8)], Params(gauss_kernel_mode=1), full=False)     # tap sums != 256: integer kernels
     np.testing.assert_array_equal(det.fetch_plane(0, "gauss7"), cvo.gaussian_blur(np.full((20, 40), 255, np.uint8), 7, 7, 1))
     det.close()
+
+
+def test_hysteresis_chain_through_many_tiles(lib):
+    """A weak edge that snakes through many 64 x 32 tiles, anchored by one strong seed: more passes than the plain launches in
+    front (one, on a fresh context) -- the rest runs inside the persistent tail kernel, which the emulated build launches as a
+    single workgroup; a second call on the same context then starts with as many plain launches as the first one needed."""
+    h, w = 160, 256
+    img = np.full((h, w), 100, np.uint8)
+    for k, y in enumerate(range(20, h - 20, 24)):
+        img[y:y + 12, 10:w - 10] = 130
+    for k, y in enumerate(range(20, h - 44, 24)):
+        x = w - 30 if k % 2 == 0 else 10
+        img[y:y + 36, x:x + 20] = 130
+    img[20:32, 10:14] = 255
+    det = Detector(0, 1, w, h, lib=lib)
+    parity.run_and_compare(det, [img], internals=False)
+    parity.run_and_compare(det, [img], internals=False)
+    det.close()

@@ -208,8 +208,10 @@ def test_capacity_overflow_is_reported_not_truncated():
 
 
 def test_hysteresis_pass_budget_growth():
-    """A weak edge that snakes through many tiles and is anchored by a single strong seed needs more hysteresis passes than
-    the initial budget: the pass is redone with a doubled budget and the result still equals the oracle exactly."""
+    """A weak edge that snakes through many tiles and is anchored by a single strong seed needs more hysteresis passes than the
+    one plain launch a fresh context starts with: the rest runs inside the persistent tail kernel (grid barriers between passes),
+    the result equals the oracle exactly; the second call starts with as many plain launches as the first one needed; and a batch
+    of such images mixed with diagrams (uneven load on the tail's workgroups) is still exact."""
     h, w = 256, 512
     img = np.full((h, w), 100, np.uint8)
     # serpentine of low-contrast steps (magnitude 4*30 = 120: weak for 50/200) ...
@@ -222,6 +224,13 @@ def test_hysteresis_pass_budget_growth():
     img[20:32, 10:14] = 255
     det = Detector(0, 1, w, h)
     parity.run_and_compare(det, [img], internals=False)
+    parity.run_and_compare(det, [img], internals=False)
+    det.close()
+    det = Detector(0, 8, w, h)
+    rng = np.random.default_rng(4)
+    batch = [img, synth.synth_diagram(1, geom=synth.GEOM_SMALL)[0], img[:, ::-1].copy(), rng.integers(0, 256, (200, 300), dtype=np.uint8),
+             img[::-1].copy(), synth.synth_diagram(2, geom=synth.GEOM_SMALL, noisy=True)[0], img.T.copy()[:256, :256], img]
+    parity.run_and_compare(det, batch, internals=False)
     det.close()
 
 

@@ -19,11 +19,11 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE = ("k_grey", "k_blur", "k_median3", "k_gauss357", "k_median57")
+STAGE = ("k_grey", "k_blur", "k_median3", "k_gauss357", "k_median57_bin", "k_median57")
 
 
 # the sources of the blur+Canny stage's kernels (and what they include)
-STAGE_SOURCES = ("i2s_types.h", "k_canny.h", "k_canny_rows.h", "k_filters.h", "tile_io.h")
+STAGE_SOURCES = ("i2s_types.h", "k_canny.h", "k_canny_rows.h", "k_filters.h", "tile_io.h", "isa/gfx950_ops.h")
 
 
 def kernels_sha():
@@ -69,12 +69,35 @@ def stage_counts(db_path, counter):
     return out
 
 
+def canny7_counts(db_path, counter):
+    """KiB of the HoughCircles x7 Sobel/NMS dispatch and the hysteresis launches behind it (up to k_edge_bins)."""
+    cur = sqlite3.connect(db_path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    ix = {c: i for i, c in enumerate(cols)}
+    kname = "kernel_name" if "kernel_name" in ix else "name"
+    disp = {}
+    for r in cur.execute("select * from counters_collection"):
+        if r[ix["counter_name"]] != counter:
+            continue
+        e = disp.setdefault(r[ix["dispatch_id"]], [short(r[ix[kname]]), int(r[ix["grid_size_x"]]), 0.0])
+        e[2] += float(r[ix["value"]])
+    order = sorted(disp)
+    sobel = [d for d in order if disp[d][0] == "k_sobel_nms_rows"]
+    if len(sobel) < 2:
+        return None
+    hc = max(sobel, key=lambda d: disp[d][1])
+    bins = [d for d in order if disp[d][0] == "k_edge_bins" and d > hc]
+    end = bins[0] if bins else order[-1] + 1
+    return sum(disp[d][2] for d in order if d == hc or (hc < d < end and disp[d][0] == "k_hysteresis"))
+
+
 def main():
     fetch_db, write_db, images, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fetch = stage_counts(fetch_db, "FETCH_SIZE")
     write = stage_counts(write_db, "WRITE_SIZE")
     total = sum(2.0 * v for v in fetch.values()) * 1024 + sum(write.values()) * 1024
     n_pix = 1024 * 1024
+    f7, w7 = canny7_counts(fetch_db, "FETCH_SIZE"), canny7_counts(write_db, "WRITE_SIZE")
     doc = {
         "source": "two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE) of `python tools/kernel_times.py --images %d "
                   "--reps 1` (one device pass of the benchmark workload), reduced by tools/pmc_traffic.py" % images,
@@ -83,6 +106,9 @@ def main():
         "images": images,
         "blur_canny_stage_kib_per_pass": {"fetch_raw": fetch, "write": write},
         "blur_canny_hbm_bytes_per_image": total / images,
+        "canny7_kib_per_pass": {"fetch_raw": f7, "write": w7},
+        "canny7_hbm_bytes_per_image": None if f7 is None else (2.0 * f7 + w7) * 1024 / images,
+        "canny7_algorithmic_bytes_per_image": 14 * n_pix,
         "algorithmic_bytes_per_image_unfused": 14 * n_pix,
         "ratio_to_algorithmic": total / images / (14 * n_pix),
     }
