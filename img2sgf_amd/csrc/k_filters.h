@@ -505,11 +505,14 @@ __global__ __launch_bounds__(256) void k_median57_bin(const ImgDesc* __restrict_
     unsigned S5 = 0, S7 = 0;                    // vertical running sums
     const BlBuf sbuf = bl_buf(im.grey);
     const int sp = im.gpitch;
-    unsigned nM, nE;
+    // two rows in flight (the kernel is bound by memory latency, not by its dozen instructions per pixel)
+    unsigned nM, nE, n2M, n2E;
     {
-        const int ro = rowoff(iclamp(y0 - 3, 0, h - 1), sp);
+        const int ro = rowoff(iclamp(y0 - 3, 0, h - 1), sp), ro2 = rowoff(iclamp(y0 - 2, 0, h - 1), sp);
         nM = bl_bload(sbuf, ro, xm);
         nE = bl_bload(sbuf, ro, xe);
+        n2M = bl_bload(sbuf, ro2, xm);
+        n2E = bl_bload(sbuf, ro2, xe);
     }
     static_assert((MB_R + 6) % 7 == 0, "the row loop is unrolled by the ring depth");
     const int t_end = imin(MB_R + 6, h + 3 - (y0 - 3));               // input rows beyond h + 2 feed no output of this band
@@ -520,10 +523,11 @@ __global__ __launch_bounds__(256) void k_median57_bin(const ImgDesc* __restrict_
             const int t = t0 + u;
             const int yi = y0 - 3 + t;                                 // input row (BORDER_REPLICATE: clamped when outside)
             const unsigned M = nM, E = nE;
+            nM = n2M; nE = n2E;
             {
-                const int ro = rowoff(iclamp(yi + 1, 0, h - 1), sp);
-                nM = bl_bload(sbuf, ro, xm);
-                nE = bl_bload(sbuf, ro, xe);
+                const int ro = rowoff(iclamp(yi + 2, 0, h - 1), sp);
+                n2M = bl_bload(sbuf, ro, xm);
+                n2E = bl_bload(sbuf, ro, xe);
             }
             // a byte is 0 or 255 iff each of its bits equals the next higher one
             const unsigned odd = (((M >> 1) ^ M) & vm) | (((E >> 1) ^ E) & ve);

@@ -118,6 +118,7 @@ static inline unsigned long long __brevll(unsigned long long v)
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi:lo} (0-3 = lo, 4-7 = hi), 0x0c = 0x00
