@@ -388,41 +388,49 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
     const size_t bin_base = (size_t)bv * g.bins;
     int* bins = s_bins[wave];
     // every wavefront works through its centres on its own: the phases below are separated by wave-level barriers only
-    // (LDS operations of one wave complete in order), so the four waves of a workgroup never wait for each other
-    for (int c = blockIdx.x * 4 + wave; c < n; c += gridDim.x * 4) {
+    // (LDS operations of one wave complete in order), so the four waves of a workgroup never wait for each other.
+    // The kernel is bound by load latency (centre -> bin counts -> records, one after the other, per centre), so the loads are
+    // pipelined across centres: while centre c is processed, the bin counts and the first 64 slots of every bin of centre c + 1
+    // are in flight (the slots are fetched WITHOUT knowing the counts: stale bytes past a bin's count are masked later), and the
+    // coordinates of centre c + 2 are on their way.
+    const int stride = gridDim.x * 4;
+    const unsigned* clist = cent_list + (size_t)bv * g.cent_cap;
+    struct Win { int nbx, nbin, my_cnt, my_bin; unsigned pre[9]; };
+    auto fetch = [&](unsigned e, Win& W) {
+        const int cxi = (int)(e & 0xffffu), cyi = (int)(e >> 16);
+        // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: at most 3 x 3 bins overlap that box
+        const int bx0 = imax(cxi - max_r, 0) / EB, bx1 = imin(cxi + max_r + 1, w - 1) / EB;
+        const int by0 = imax(cyi - max_r, 0) / EB, by1 = imin(cyi + max_r + 1, h - 1) / EB;
+        W.nbx = bx1 - bx0 + 1; W.nbin = W.nbx * (by1 - by0 + 1);          // <= 9
+        W.my_cnt = 0; W.my_bin = 0;
+        if (lane < W.nbin) {
+            W.my_bin = (int)(bin_base + (size_t)(by0 + lane / W.nbx) * g.bw + (bx0 + lane % W.nbx));
+            W.my_cnt = bin_cnt[W.my_bin];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            W.pre[q] = 0xffffffffu;
+            if (q < W.nbin) W.pre[q] = bin_ent[(size_t)__builtin_amdgcn_readlane(W.my_bin, q) * EB_CAP + lane].x;
+        }
+    };
+    int c = blockIdx.x * 4 + wave;
+    unsigned e_cur = c < n ? clist[c] : 0u, e_next = c + stride < n ? clist[c + stride] : 0u;
+    Win cur, nxt;
+    if (c < n) fetch(e_cur, cur);
+    for (; c < n; c += stride) {
+        const unsigned e_next2 = c + 2 * stride < n ? clist[c + 2 * stride] : 0u;
+        if (c + stride < n) fetch(e_next, nxt);
         for (int i = lane; i < RAD_BINS_MAX; i += 64) bins[i] = 0;
         __builtin_amdgcn_wave_barrier();
-        int cxi = 0, cyi = 0;
+        const int cxi = (int)(e_cur & 0xffffu), cyi = (int)(e_cur >> 16);
         {
-            const unsigned e = cent_list[(size_t)bv * g.cent_cap + c];
-            cxi = (int)(e & 0xffffu); cyi = (int)(e >> 16);
-            // pixels with minR^2 <= d^2 <= maxR^2 lie within max_r of the centre: at most 3 x 3 bins overlap that box.
-            // Lane q fetches bin q's count, then all record loads of all bins are issued before any is consumed.
-            const int bx0 = imax(cxi - max_r, 0) / EB, bx1 = imin(cxi + max_r + 1, w - 1) / EB;
-            const int by0 = imax(cyi - max_r, 0) / EB, by1 = imin(cyi + max_r + 1, h - 1) / EB;
-            const int nbx = bx1 - bx0 + 1, nbin = nbx * (by1 - by0 + 1);        // <= 9
-            int my_cnt = 0, my_bin = 0;
-            if (lane < nbin) {
-                my_bin = (int)(bin_base + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx));
-                my_cnt = bin_cnt[my_bin];
-            }
-            unsigned pre[9];
-            int cnt[9];
 #pragma unroll
             for (int q = 0; q < 9; q++) {
-                pre[q] = 0xffffffffu; cnt[q] = 0;
-                if (q < nbin) {
-                    cnt[q] = __builtin_amdgcn_readlane(my_cnt, q);
-                    const uint2* ent = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, q) * EB_CAP;
-                    if (lane < cnt[q]) pre[q] = ent[lane].x;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 9; q++) {
-                if (q >= nbin) continue;
-                const uint2* ent = bin_ent + (size_t)__builtin_amdgcn_readlane(my_bin, q) * EB_CAP;
-                for (int k = lane; k < cnt[q]; k += 64) {
-                    const unsigned xy = k < 64 ? pre[q] : ent[k].x;
+                if (q >= cur.nbin) continue;
+                const int cnt_q = __builtin_amdgcn_readlane(cur.my_cnt, q);
+                const uint2* ent = bin_ent + (size_t)__builtin_amdgcn_readlane(cur.my_bin, q) * EB_CAP;
+                for (int k = lane; k < cnt_q; k += 64) {
+                    const unsigned xy = k < 64 ? cur.pre[q] : ent[k].x;
                     const int dxi = cxi - (int)(xy & 0xffffu), dyi = cyi - (int)(xy >> 16);
                     const int K = __mul24(dxi, dxi + 1) + __mul24(dyi, dyi + 1);
                     if (K >= k_lo && K < k_hi) atomicAdd(&bins[s_lut[K >> 1]], 1);
@@ -496,6 +504,7 @@ __global__ __launch_bounds__(256) void k_radius(const ImgDesc* __restrict__ desc
             }
         }
         __builtin_amdgcn_wave_barrier();
+        e_cur = e_next; e_next = e_next2; cur = nxt;
     }
 }
 
