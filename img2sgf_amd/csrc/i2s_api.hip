@@ -77,7 +77,7 @@ struct i2s_ctx {
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
     int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
-    int* d_chg = nullptr;        // [NMAP][nb][tiles] last hysteresis pass (+1) that changed the tile
+    int* d_chg = nullptr;        // [2 (pass parity)][NMAP][nb][tiles] (last hysteresis pass that changed the tile + 1) << 4 | borders changed
     int* d_mflags = nullptr;     // [nb][bands_y][bands_x] k_median57_bin: the band holds a pixel other than 0 / 255
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
@@ -207,7 +207,7 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_tl_cnt, nb * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(unsigned short)));
     I2S_HIP(hipMalloc(&ctx->d_weak, 2 * (nb * NMAP * g.tiles + 1) * sizeof(int)));
-    I2S_HIP(hipMalloc(&ctx->d_chg, nb * NMAP * g.tiles * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_chg, 2 * nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_mflags, nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
     ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
@@ -352,11 +352,12 @@ static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
     uint8_t* maps = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
     uint8_t* edges = phase == 0 ? plane_ptr(ctx, I2S_PLANE_EDGES) : (uint8_t*)nullptr;
     const int k = ctx->hyst_k[phase];
+    const size_t chg_half = (size_t)ctx->max_batch * NMAP * ctx->geo.tiles;
     for (int pass = 0; pass < k; pass++)
         hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, pass,
-                           worklist(ctx, phase), ctx->d_chg);
+                           worklist(ctx, phase), ctx->d_chg, chg_half);
     hipLaunchKernelGGL(k_hysteresis_tail, dim3(HY_TAIL_BLOCKS), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, k,
-                       HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, counter, info);
+                       HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, chg_half, counter, info);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
@@ -430,7 +431,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, (2 * HYST_MAX_PASSES + 4) * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 0), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 1), 0, sizeof(int), st));
-        I2S_HIP(hipMemsetAsync(ctx->d_chg, 0, (size_t)ctx->max_batch * NMAP * g.tiles * sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(ctx->d_chg, 0, (size_t)2 * ctx->max_batch * NMAP * g.tiles * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_mflags, 0, (size_t)nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);

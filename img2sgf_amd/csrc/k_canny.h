@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict
 // whole tiles, spent a third of their GPU time in the previous byte-per-thread version (up to 300 us per launch).
 // The host launches passes back to back; a pass returns at once when the previous pass changed nothing anywhere
 // (flags[pass-1] == 0), and from pass 1 on a tile is revisited only if it or one of its 8 neighbours changed in the previous
-// pass (chg[tile] == index of the last pass that changed it, + 1).  The result is the unique fixed point, independent of
+// pass on a border that faces it (chg[tile] = (index of the last pass that changed it + 1) << 4 | borders it changed).  The result is the unique fixed point, independent of
 // scheduling and of the list order.
 // maps points at map 0; map m of image b at (m * nb + b) * slot.  `edges` (non-null for the main Canny's phase, whose worklist
 // holds map-0 tiles only) receives 255 / 0 for every rewritten dword: together with the NMS kernel's output that is the edge
@@ -149,8 +149,13 @@ __device__ __forceinline__ unsigned long long hy_fill_up(unsigned long long S, u
 // one pass over this workgroup's share of the worklist (entries first, first + stride, ...; one wavefront per entry)
 __device__ __forceinline__ void hysteresis_pass(const ImgDesc* __restrict__ desc, const Geo& g, uint8_t* __restrict__ maps,
                                                 uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
-                                                const int* __restrict__ wl, int* __restrict__ chg)
+                                                const int* __restrict__ wl, int* __restrict__ chg2, size_t chg_half)
 {
+    // two copies of the per-tile record, by pass parity: a pass READS what the previous pass wrote and WRITES its own copy, so a
+    // tile that changes again in this pass (perhaps in its interior only) cannot wipe out the border bits its neighbours have
+    // yet to look at
+    const int* chg_prev = chg2 + (size_t)((pass + 1) & 1) * chg_half;
+    int* chg = chg2 + (size_t)(pass & 1) * chg_half;
     const int nwl = wl[0];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int e = blockIdx.x * 4 + wave; e < nwl; e += gridDim.x * 4) {
@@ -162,12 +167,21 @@ __device__ __forceinline__ void hysteresis_pass(const ImgDesc* __restrict__ desc
         const int x0 = tx_ * CT_W, y0 = ty_ * CT_H;
         const size_t tbase = (size_t)mb * g.tiles;
         if (pass > 0) {
-            // revisit only if this tile or one of its 8 neighbours changed in the previous pass (lane k looks at neighbour k)
+            // A tile left its last visit at its local fixed point: it has to be looked at again only if its APRON changed, i.e. if
+            // in the previous pass a neighbour promoted pixels on the border that faces this tile -- the bottom row of the tile
+            // above, the right column of the tile to the left, the bottom-right pixel (bottom row AND right column) of the tile
+            // above left ...  chg[tile] = (pass + 1) << 4 | borders changed (1 top row, 2 bottom row, 4 left column, 8 right column).
+            // Lane k looks at neighbour k (its own entry, k = 4, never asks for a visit).
             bool hit = false;
-            if (lane < 9) {
+            if (lane < 9 && lane != 4) {
                 const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
-                const int tx = tx_ + lane % 3 - 1, ty = ty_ + lane / 3 - 1;
-                hit = tx >= 0 && tx < ntx && ty >= 0 && ty < nty && chg[tbase + ty * g.tw + tx] == pass;
+                const int ddx = lane % 3 - 1, ddy = lane / 3 - 1;
+                const int tx = tx_ + ddx, ty = ty_ + ddy;
+                const int need = (ddy < 0 ? 2 : (ddy > 0 ? 1 : 0)) | (ddx < 0 ? 8 : (ddx > 0 ? 4 : 0));
+                if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty) {
+                    const int v = chg_prev[tbase + ty * g.tw + tx];
+                    hit = (v >> 4) == pass && (v & need) == need;
+                }
             }
             if (__ballot(hit) == 0ull) continue;
         }
@@ -224,7 +238,10 @@ __device__ __forceinline__ void hysteresis_pass(const ImgDesc* __restrict__ desc
             if (__ballot(changed) == 0ull) break;
         }
         const unsigned long long promoted = core ? (S & ~S0) : 0ull;
-        if (__ballot(promoted != 0ull) == 0ull) continue;
+        const unsigned long long rows_changed = __ballot(promoted != 0ull);      // bit r = lane r = tile row r - 1
+        if (rows_changed == 0ull) continue;
+        const int borders = (int)((rows_changed >> 1) & 1ull) | ((int)((rows_changed >> CT_H) & 1ull) << 1) |
+                            (__ballot((promoted & 1ull) != 0ull) ? 4 : 0) | (__ballot((promoted >> 63) != 0ull) ? 8 : 0);
         if (promoted) {
             uint8_t* row = mp + rowoff(y, g.pitch) + x0;
             uint8_t* erow = edges ? edges + (size_t)mb * g.slot + rowoff(y, g.pitch) + x0 : nullptr;      // mb == b in the main phase
@@ -244,17 +261,17 @@ __device__ __forceinline__ void hysteresis_pass(const ImgDesc* __restrict__ desc
                 }
             }
         }
-        if (lane == 0) { flags[pass] = 1; chg[tbase + tile] = pass + 1; }
+        if (lane == 0) { flags[pass] = 1; chg[tbase + tile] = ((pass + 1) << 4) | borders; }
     }
 }
 
 __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
                                                     uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
-                                                    const int* __restrict__ wl, int* __restrict__ chg)
+                                                    const int* __restrict__ wl, int* __restrict__ chg, size_t chg_half)
 {
     static_assert(CT_W == 64 && CT_H + 2 <= 64, "one 64-bit mask per row, one lane per row incl. the apron");
     if (pass > 0 && flags[pass - 1] == 0) return;
-    hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg);
+    hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg, chg_half);
 }
 
 // The tail of a phase: ONE launch behind the `first_pass` plain launches (a number the host adapts to what the previous calls
@@ -265,8 +282,8 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
 // once: a phase costs first_pass + 1 launches instead of a fixed budget of six.
 __global__ __launch_bounds__(256) void k_hysteresis_tail(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
                                                          uint8_t* __restrict__ edges, int* __restrict__ flags, int first_pass, int max_pass,
-                                                         const int* __restrict__ wl, int* __restrict__ chg, int* __restrict__ counter,
-                                                         int* __restrict__ info)
+                                                         const int* __restrict__ wl, int* __restrict__ chg, size_t chg_half,
+                                                         int* __restrict__ counter, int* __restrict__ info)
 {
     __shared__ int s_ok;
     int target = 0;
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256) void k_hysteresis_tail(const ImgDesc* __restri
     bool ok = true;
     for (; pass < max_pass; pass++) {
         if (load_agent(&flags[pass - 1]) == 0) break;                    // the previous pass changed nothing: fixed point
-        hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg);
+        hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg, chg_half);
         ok = grid_barrier(counter, target, &s_ok);
         if (!ok) break;
     }
