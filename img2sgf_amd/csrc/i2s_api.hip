@@ -75,7 +75,7 @@ struct i2s_ctx {
     int je_max_rounds = 2048;    // beyond this a pass is handed to the serial decoder (i2s_jpeg_set_max_rounds)
     float jpeg_ms[4] = {0, 0, 0, 0};     // last i2s_detect_jpeg_batch: parsing | entropy stage, host work | entropy stage, waiting for the device | whole call
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
-    unsigned short* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP]
+    TlBox* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP] box, plus centre and index of the circles that touch the tile
     int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
     int* d_chg = nullptr;        // [2 (pass parity)][NMAP][nb][tiles] (last hysteresis pass that changed the tile + 1) << 4 | borders changed
     int* d_mflags = nullptr;     // [nb][bands_y][bands_x] k_median57_bin: the band holds a pixel other than 0 / 255
@@ -205,7 +205,7 @@ static int create_impl(i2s_ctx* ctx)
     const size_t nb = ctx->max_batch;
     I2S_HIP(hipMalloc(&ctx->d_lsum, nb * sizeof(unsigned long long)));
     I2S_HIP(hipMalloc(&ctx->d_tl_cnt, nb * g.tiles * sizeof(int)));
-    I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(unsigned short)));
+    I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(TlBox)));
     I2S_HIP(hipMalloc(&ctx->d_weak, 2 * (nb * NMAP * g.tiles + 1) * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_chg, 2 * nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_mflags, nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int)));

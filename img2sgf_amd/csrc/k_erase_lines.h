@@ -15,10 +15,14 @@ constexpr int TL_CAP = 64;       // circles listed per 64x32 tile; a tile touche
 
 // Concatenate the per-variant circle lists into the reference's `circles` array order (slots of the blur bank,
 // img2sgf.py:171-186) and bin the circles' erase boxes by 64x32 tile: tl_cnt[b * g.tiles + tile] (may exceed TL_CAP =
-// overflow marker), tl_idx[(b * g.tiles + tile) * TL_CAP + k] = circle index.  grid (nb), block 256.
+// overflow marker), tl_box[(b * g.tiles + tile) * TL_CAP + k] = everything k_erase_lines needs of the circle -- its box (clipped to
+// the image), the centre of its plus and its index -- so that the tile kernel has ONE load between itself and its circles instead of
+// the chain count -> index -> circle.  grid (nb), block 256.
+struct TlBox { short lo_x, hi_x, lo_y, hi_y, mx, my; unsigned short idx, pad; };
+static_assert(sizeof(TlBox) == 16, "one 16-byte load per record");
 __global__ __launch_bounds__(256) void k_concat_circles(const ImgDesc* __restrict__ desc, Geo g, const float* __restrict__ vcirc,
                                                         const int* __restrict__ vcount, const int* __restrict__ overflow,
-                                                        i2s_result* __restrict__ res, int* __restrict__ tl_cnt, unsigned short* __restrict__ tl_idx)
+                                                        i2s_result* __restrict__ res, int* __restrict__ tl_cnt, TlBox* __restrict__ tl_box)
 {
     __shared__ int s_off[NSLOT + 1];
     const int b = blockIdx.x;
@@ -55,11 +59,15 @@ __global__ __launch_bounds__(256) void k_concat_circles(const ImgDesc* __restric
             const int lo_x = imax(imin(bx0, bx1), 0), hi_x = imin(imax(bx0, bx1), w - 1);
             const int lo_y = imax(imin(by0, by1), 0), hi_y = imin(imax(by0, by1), h - 1);
             if (lo_x > hi_x || lo_y > hi_y) continue;
+            TlBox rec;
+            rec.lo_x = (short)lo_x; rec.hi_x = (short)hi_x; rec.lo_y = (short)lo_y; rec.hi_y = (short)hi_y;
+            rec.mx = (short)iclamp(__float2int_rn(xc), -32768, 32767); rec.my = (short)iclamp(__float2int_rn(yc), -32768, 32767);
+            rec.idx = (unsigned short)(s_off[s] + i); rec.pad = 0;
             for (int ty = lo_y / ET_H; ty <= hi_y / ET_H; ty++)
                 for (int tx = lo_x / ET_W; tx <= hi_x / ET_W; tx++) {
                     const size_t t = (size_t)b * g.tiles + (size_t)ty * g.tw + tx;
                     const int k = atomicAdd(&tl_cnt[t], 1);
-                    if (k < TL_CAP) tl_idx[t * TL_CAP + k] = (unsigned short)(s_off[s] + i);
+                    if (k < TL_CAP) tl_box[t * TL_CAP + k] = rec;
                 }
         }
     }
@@ -76,15 +84,15 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
                                                      const uint8_t* __restrict__ edges, uint8_t* __restrict__ removed,
                                                      const i2s_result* __restrict__ res, HoughTrig trig,
                                                      int* __restrict__ lacc, int lrow, int gx, int gy,
-                                                     const int* __restrict__ tl_cnt, const unsigned short* __restrict__ tl_idx)
+                                                     const int* __restrict__ tl_cnt, const TlBox* __restrict__ tl_box)
 {
-    __shared__ short s_box[256][4];
-    __shared__ int s_idx[256];
+    __shared__ TlBox s_box[256];
     __shared__ int s_n;
     __shared__ int s_hist[LROWS][LB];
     __shared__ int s_rmin[LROWS];
     __shared__ unsigned short s_nz[ET_W * ET_H];
     __shared__ float s_cos[LROWS], s_sin[LROWS];
+    static_assert(I2S_MAX_CIRCLES <= (1 << 16) && TL_CAP <= 256, "circle index | list position packed into one int");
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z;
     const int w = desc[b].w, h = desc[b].h;
@@ -94,6 +102,27 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     const i2s_result* R = res + b;
     const int nc = R->n_circles;
     const int half = w + h;   // (numrho - 1) / 2
+    // this thread's 8 pixels: 4 consecutive columns x0 + 4 * (tid & 15) .. + 3 on the two rows y0 + (tid >> 4) and + 16 (dword
+    // loads / stores of the planes; per circle one strip test, then 4 column and 2 row tests)
+    const int lx0 = 4 * (tid & 15), ly0 = tid >> 4;
+    const uint8_t* e = edges + (size_t)b * g.slot;
+    uint8_t* o = removed + (size_t)b * g.slot;
+    // every global load of the tile is requested up front (the kernel is a chain of latencies otherwise): the count of the tile's
+    // circle list, the list's records WITHOUT waiting for the count (slots past it hold stale bytes, masked below), the edge pixels
+    const size_t tslot = (size_t)b * g.tiles + (size_t)tl.ty * g.tw + tl.tx;
+    const int tcnt = nc > 0 ? tl_cnt[tslot] : 0;
+    TlBox myrec = TlBox{0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < TL_CAP) myrec = tl_box[tslot * TL_CAP + tid];
+    unsigned ev2[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int px = x0 + lx0, py = y0 + ly0 + 16 * k;
+        if (px < w && py < h) {
+            const int off = rowoff(py, g.pitch) + px;
+            if (px + 3 < w) ev2[k] = *reinterpret_cast<const unsigned*>(e + off);
+            else for (int q = 0; q < 4 && px + q < w; q++) ev2[k] |= (unsigned)e[off + q] << (8 * q);
+        }
+    }
     for (int i = tid; i < LROWS * LB; i += 256) (&s_hist[0][0])[i] = 0;
     if (tid < LROWS) {
         const int c = tid / LANG, n = tid % LANG;
@@ -110,60 +139,82 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         s_cos[tid] = n < trig.n[c] ? trig.cos_[c][n] : 0.f;
         s_sin[tid] = n < trig.n[c] ? trig.sin_[c][n] : 0.f;
     }
-    // this thread's 8 pixels: 4 consecutive columns x0 + 4 * (tid & 15) .. + 3 on the two rows y0 + (tid >> 4) and + 16 (dword
-    // loads / stores of the planes; per circle one strip test, then 4 column and 2 row tests)
+    // best[k][q] = (largest index of a circle whose box covers the pixel) << 8 | its position in s_box, -1 if none
     int best[2][4];
 #pragma unroll
     for (int k = 0; k < 2; k++)
 #pragma unroll
         for (int q = 0; q < 4; q++) best[k][q] = -1;
-    const int lx0 = 4 * (tid & 15), ly0 = tid >> 4;
+    auto cover = [&](int n) {
+        const int px = x0 + lx0, py = y0 + ly0;
+        for (int j = 0; j < n; j++) {
+            const int bx0 = s_box[j].lo_x, bx1 = s_box[j].hi_x;
+            if (px + 3 < bx0 || px > bx1) continue;
+            const int by0 = s_box[j].lo_y, by1 = s_box[j].hi_y, key = ((int)s_box[j].idx << 8) | j;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int yy = py + 16 * k;
+                if (yy < by0 || yy > by1) continue;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (px + q >= bx0 && px + q <= bx1) best[k][q] = imax(best[k][q], key);
+            }
+        }
+    };
     // circles whose erase box touches this tile: the per-tile list built by k_concat_circles (order irrelevant: the
     // largest index wins), or every circle of the image when that list overflowed
-    const size_t tslot = (size_t)b * g.tiles + (size_t)tl.ty * g.tw + tl.tx;
-    const int tcnt = nc > 0 ? tl_cnt[tslot] : 0;
     const bool listed = tcnt <= TL_CAP;
-    const int ncand = listed ? tcnt : nc;
-    for (int base = 0; base < ncand; base += 256) {
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        if (base + tid < ncand) {
-            const int i = listed ? (int)tl_idx[tslot * TL_CAP + base + tid] : base + tid;
-            const float xc = R->circles[i][0], yc = R->circles[i][1];
-            const float r = R->circles[i][2] + 2.0f;
-            const int bx0 = __float2int_rn(xc - r), by0 = __float2int_rn(yc - r);
-            const int bx1 = __float2int_rn(xc + r), by1 = __float2int_rn(yc + r);
-            const int lo_x = imin(bx0, bx1), hi_x = imax(bx0, bx1), lo_y = imin(by0, by1), hi_y = imax(by0, by1);
-            if (hi_x >= x0 && lo_x < x0 + ET_W && hi_y >= y0 && lo_y < y0 + ET_H) {
-                const int k = atomicAdd(&s_n, 1);
-                s_box[k][0] = (short)iclamp(lo_x, -32768, 32767); s_box[k][1] = (short)iclamp(hi_x, -32768, 32767);
-                s_box[k][2] = (short)iclamp(lo_y, -32768, 32767); s_box[k][3] = (short)iclamp(hi_y, -32768, 32767);
-                s_idx[k] = i;
-            }
-        }
-        __syncthreads();
-        const int n = s_n;
-        {
-            const int px = x0 + lx0, py = y0 + ly0;
-            for (int j = 0; j < n; j++) {
-                const int bx0 = s_box[j][0], bx1 = s_box[j][1];
-                if (px + 3 < bx0 || px > bx1) continue;
-                const int by0 = s_box[j][2], by1 = s_box[j][3], idx = s_idx[j];
+    int mxy[2][4];                                      // centre of the deciding circle's plus, packed (overflow path: resolved per chunk)
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int yy = py + 16 * k;
-                    if (yy < by0 || yy > by1) continue;
+    for (int k = 0; k < 2; k++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (px + q >= bx0 && px + q <= bx1) best[k][q] = imax(best[k][q], idx);
+        for (int q = 0; q < 4; q++) mxy[k][q] = 0;
+    if (listed) {
+        if (tid < tcnt) s_box[tid] = myrec;
+        __syncthreads();
+        cover(tcnt);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (best[k][q] >= 0) { const TlBox& r = s_box[best[k][q] & 0xff]; mxy[k][q] = ((int)r.mx << 16) | ((int)r.my & 0xffff); }
+    } else {
+        for (int base = 0; base < nc; base += 256) {
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            if (base + tid < nc) {
+                const int i = base + tid;
+                const float xc = R->circles[i][0], yc = R->circles[i][1];
+                const float r = R->circles[i][2] + 2.0f;
+                const int bx0 = __float2int_rn(xc - r), by0 = __float2int_rn(yc - r);
+                const int bx1 = __float2int_rn(xc + r), by1 = __float2int_rn(yc + r);
+                const int lo_x = imin(bx0, bx1), hi_x = imax(bx0, bx1), lo_y = imin(by0, by1), hi_y = imax(by0, by1);
+                if (hi_x >= x0 && lo_x < x0 + ET_W && hi_y >= y0 && lo_y < y0 + ET_H) {
+                    const int k = atomicAdd(&s_n, 1);
+                    TlBox rec;
+                    rec.lo_x = (short)iclamp(lo_x, -32768, 32767); rec.hi_x = (short)iclamp(hi_x, -32768, 32767);
+                    rec.lo_y = (short)iclamp(lo_y, -32768, 32767); rec.hi_y = (short)iclamp(hi_y, -32768, 32767);
+                    rec.mx = (short)iclamp(__float2int_rn(xc), -32768, 32767); rec.my = (short)iclamp(__float2int_rn(yc), -32768, 32767);
+                    rec.idx = (unsigned short)i; rec.pad = 0;
+                    s_box[k] = rec;
                 }
             }
+            __syncthreads();
+            int before[2][4];
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) before[k][q] = best[k][q];
+            cover(s_n);
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (best[k][q] != before[k][q]) { const TlBox& r = s_box[best[k][q] & 0xff]; mxy[k][q] = ((int)r.mx << 16) | ((int)r.my & 0xffff); }
         }
-        __syncthreads();
     }
-    if (ncand == 0) __syncthreads();   // s_hist / s_rmin initialisation
-    const uint8_t* e = edges + (size_t)b * g.slot;
-    uint8_t* o = removed + (size_t)b * g.slot;
+    __syncthreads();                                    // s_hist / s_rmin initialisation; everybody is done with s_box
     if (tid == 0) s_n = 0;
     __syncthreads();
 #pragma unroll
@@ -173,15 +224,13 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         if (px >= w || py >= h) continue;
         const int off = rowoff(py, g.pitch) + px;
         const bool whole = px + 3 < w;
-        unsigned ev;
-        if (whole) ev = *reinterpret_cast<const unsigned*>(e + off);
-        else { ev = 0; for (int q = 0; q < 4 && px + q < w; q++) ev |= (unsigned)e[off + q] << (8 * q); }
+        const unsigned ev = ev2[k];
         unsigned outw = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             unsigned val = (ev >> (8 * q)) & 0xffu;
             if (best[k][q] >= 0) {
-                const int mx = __float2int_rn(R->circles[best[k][q]][0]), my = __float2int_rn(R->circles[best[k][q]][1]);
+                const int mx = mxy[k][q] >> 16, my = (int)(short)(mxy[k][q] & 0xffff);
                 const bool plus = (px + q == mx && iabs_(py - my) <= 1) || (py == my && iabs_(px + q - mx) <= 1);
                 val = plus ? 255u : 0u;
             }
