@@ -522,8 +522,9 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
 
         hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, ctx->d_desc, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res,
                            ctx->d_tl_cnt, ctx->d_tl_idx);
-        hipLaunchKernelGGL(k_erase_lines, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
-                           plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, fx, fy, ctx->d_tl_cnt, ctx->d_tl_idx);
+        const int ex = cdiv(wmax, ET_W), ey = cdiv(hmax, ET_H);         // 64 x 64 tiles
+        hipLaunchKernelGGL(k_erase_lines, dim3((unsigned)ex * ey * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
+                           plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, ex, ey, ctx->d_tl_cnt, ctx->d_tl_idx);
         hipLaunchKernelGGL(k_line_peaks, dim3(nb), b256, 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
         I2S_SEG(13);
@@ -804,7 +805,7 @@ extern "C" int i2s_find_lines(i2s_ctx* ctx, const uint8_t* image, int w, int h, 
     d.src = nullptr; d.w = w; d.h = h; d.sstride = w; d.cn = 1;
     d.line_thr = hr->line_threshold = p->line_threshold > 0 ? p->line_threshold : i2s_choose_threshold(w, h);
     d.gpitch = g.pitch; d.grey = plane_ptr(ctx, I2S_PLANE_GREY);
-    const int fx = cdiv(w, FT_W), fy = cdiv(h, FT_H);
+    const int fx = cdiv(w, ET_W), fy = cdiv(h, ET_H);
     hipError_t e[8];
     e[0] = hipMemcpyAsync(ctx->d_desc, ctx->h_desc, sizeof(ImgDesc), hipMemcpyHostToDevice, st);
     e[1] = hipMemcpyAsync(ctx->d_res, hr, sizeof(i2s_result), hipMemcpyHostToDevice, st);          // no circles: nothing is erased

@@ -6,7 +6,8 @@
 namespace i2s {
 
 constexpr int ET_W = 64;
-constexpr int ET_H = 32;
+constexpr int ET_H = 64;          // (32 in rounds 1-2: the per-tile set-up and flush cost as much as the pixels)
+constexpr int ET_K = ET_H / 16;   // rows per thread: y0 + (tid >> 4) + 16 k
 constexpr int LB = 128;          // LDS histogram bins per (call, angle) per tile
 constexpr int LANG = 4;          // angle rows reserved per HoughLines call
 constexpr int LROWS = 3 * LANG;  // accumulator rows per image
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     const i2s_result* R = res + b;
     const int nc = R->n_circles;
     const int half = w + h;   // (numrho - 1) / 2
-    // this thread's 8 pixels: 4 consecutive columns x0 + 4 * (tid & 15) .. + 3 on the two rows y0 + (tid >> 4) and + 16 (dword
+    // this thread's 4 ET_K pixels: 4 consecutive columns x0 + 4 * (tid & 15) .. + 3 on the rows y0 + (tid >> 4) + 16 k (dword
     // loads / stores of the planes; per circle one strip test, then 4 column and 2 row tests)
     const int lx0 = 4 * (tid & 15), ly0 = tid >> 4;
     const uint8_t* e = edges + (size_t)b * g.slot;
@@ -113,9 +114,11 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     const int tcnt = nc > 0 ? tl_cnt[tslot] : 0;
     TlBox myrec = TlBox{0, 0, 0, 0, 0, 0, 0, 0};
     if (tid < TL_CAP) myrec = tl_box[tslot * TL_CAP + tid];
-    unsigned ev2[2] = {0u, 0u};
+    unsigned ev2[ET_K];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < ET_K; k++) ev2[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < ET_K; k++) {
         const int px = x0 + lx0, py = y0 + ly0 + 16 * k;
         if (px < w && py < h) {
             const int off = rowoff(py, g.pitch) + px;
@@ -140,9 +143,9 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         s_sin[tid] = n < trig.n[c] ? trig.sin_[c][n] : 0.f;
     }
     // best[k][q] = (largest index of a circle whose box covers the pixel) << 8 | its position in s_box, -1 if none
-    int best[2][4];
+    int best[ET_K][4];
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < ET_K; k++)
 #pragma unroll
         for (int q = 0; q < 4; q++) best[k][q] = -1;
     auto cover = [&](int n) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
             if (px + 3 < bx0 || px > bx1) continue;
             const int by0 = s_box[j].lo_y, by1 = s_box[j].hi_y, key = ((int)s_box[j].idx << 8) | j;
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < ET_K; k++) {
                 const int yy = py + 16 * k;
                 if (yy < by0 || yy > by1) continue;
 #pragma unroll
@@ -164,9 +167,9 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     // circles whose erase box touches this tile: the per-tile list built by k_concat_circles (order irrelevant: the
     // largest index wins), or every circle of the image when that list overflowed
     const bool listed = tcnt <= TL_CAP;
-    int mxy[2][4];                                      // centre of the deciding circle's plus, packed (overflow path: resolved per chunk)
+    int mxy[ET_K][4];                                      // centre of the deciding circle's plus, packed (overflow path: resolved per chunk)
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < ET_K; k++)
 #pragma unroll
         for (int q = 0; q < 4; q++) mxy[k][q] = 0;
     if (listed) {
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
         __syncthreads();
         cover(tcnt);
 #pragma unroll
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < ET_K; k++)
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (best[k][q] >= 0) { const TlBox& r = s_box[best[k][q] & 0xff]; mxy[k][q] = ((int)r.mx << 16) | ((int)r.my & 0xffff); }
@@ -201,14 +204,14 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
                 }
             }
             __syncthreads();
-            int before[2][4];
+            int before[ET_K][4];
 #pragma unroll
-            for (int k = 0; k < 2; k++)
+            for (int k = 0; k < ET_K; k++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) before[k][q] = best[k][q];
             cover(s_n);
 #pragma unroll
-            for (int k = 0; k < 2; k++)
+            for (int k = 0; k < ET_K; k++)
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                     if (best[k][q] != before[k][q]) { const TlBox& r = s_box[best[k][q] & 0xff]; mxy[k][q] = ((int)r.mx << 16) | ((int)r.my & 0xffff); }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
     if (tid == 0) s_n = 0;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < ET_K; k++) {
         const int ly = ly0 + 16 * k;
         const int px = x0 + lx0, py = y0 + ly;
         if (px >= w || py >= h) continue;
