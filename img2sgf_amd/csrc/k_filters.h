@@ -645,61 +645,74 @@ __device__ __forceinline__ void bs_col5(const unsigned (&t)[5], unsigned& o0, un
 // significant first, four bits each; a loop, not unrolled code: eight unrolled rounds of two medians are 40 KB of instructions);
 // round i leaves its result -- bit (k - K/2) = that bit of the median of the pixel at window bit k, k = 4 .. 27 -- in
 // s_res[i * 256 + thread].
+// one round: plane p of the K window rows starting at `rows`; FIRST = no candidate has been excluded yet (plane 7's round),
+// LAST = nobody will look at the candidates or the rank again
+template <int K, bool FIRST, bool LAST>
+__device__ __forceinline__ void bs_round(const unsigned long long* __restrict__ rows, int p, int sh, unsigned (&cand)[K][K], unsigned (&m)[6],
+                                         unsigned* __restrict__ s_res_i)
+{
+    unsigned W[K];
+#pragma unroll
+    for (int dy = 0; dy < K; dy++) {
+        const unsigned long long v = rows[p * M_ROWS + dy];
+        W[dy] = __builtin_amdgcn_alignbit((unsigned)(v >> 32), (unsigned)v, (unsigned)sh);
+    }
+    unsigned v0[K], v1[K], v2[K];
+#pragma unroll
+    for (int dx = 0; dx < K; dx++) {
+        unsigned t[K];
+#pragma unroll
+        for (int dy = 0; dy < K; dy++) t[dy] = FIRST ? W[dy] : (cand[dy][dx] & W[dy]);
+        if (K == 7) bs_col7(reinterpret_cast<const unsigned (&)[7]>(t), v0[dx], v1[dx], v2[dx]);
+        else bs_col5(reinterpret_cast<const unsigned (&)[5]>(t), v0[dx], v1[dx], v2[dx]);
+        // onto the output's column: the element at offset dx of the window that starts at column a sits at column a + dx
+        if (dx) { v0[dx] >>= dx; v1[dx] >>= dx; v2[dx] >>= dx; }
+    }
+    unsigned c[6];
+    if (K == 7) bs_sum7(reinterpret_cast<const unsigned (&)[7]>(v0), reinterpret_cast<const unsigned (&)[7]>(v1), reinterpret_cast<const unsigned (&)[7]>(v2), c);
+    else bs_sum5(reinterpret_cast<const unsigned (&)[5]>(v0), reinterpret_cast<const unsigned (&)[5]>(v1), reinterpret_cast<const unsigned (&)[5]>(v2), c);
+    // m - c: the final borrow says c > m, i.e. at least `rank` candidates have a 1: the median's bit is 1
+    unsigned dif[6], bor = 0u;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        dif[b] = bitop3<0x96>(m[b], c[b], bor);
+        bor = bitop3<0x8E>(m[b], c[b], bor);                                // (~m & (c | bor)) | (c & bor)
+    }
+    const unsigned ge = bor;
+    *s_res_i = ge;
+    if (LAST) return;
+#pragma unroll
+    for (int b = 0; b < 6; b++) m[b] = bitop3<0xCA>(ge, m[b], dif[b]);       // ge ? m : m - c -- bit 0: the c candidates with a 1 are larger than the median
+#pragma unroll
+    for (int dx = 0; dx < K; dx++) {
+        const unsigned gsh = ge << dx;
+#pragma unroll
+        for (int dy = 0; dy < K; dy++)                                      // cand & ~(plane ^ bit)
+            cand[dy][dx] = FIRST ? ~(W[dy] ^ gsh) : bitop3<0x90>(cand[dy][dx], W[dy], gsh);
+    }
+}
+
+// The K x K medians of 24 pixels of tile row `row` (output row index; its window rows are plane rows row + 3 - K/2 ..), whose
+// 32-bit window of the plane row words starts at bit `sh` (0 or 24).  One round per LIVE plane (live_list: their numbers, most
+// significant first, four bits each; plane 7 is always the first, the others run in a loop, not as unrolled code: eight unrolled
+// rounds of two medians are 40 KB of instructions); round i leaves its result -- bit (k - K/2) = that bit of the median of the
+// pixel at window bit k, k = 4 .. 27 -- in s_res[i * 256 + thread].
 template <int K>
 __device__ __forceinline__ void bs_median_row(const unsigned long long* __restrict__ s_pl, int row, int sh, int nlive, unsigned live_list,
                                               unsigned* __restrict__ s_res)
 {
     constexpr int R = K / 2;
     unsigned cand[K][K];
-#pragma unroll
-    for (int dy = 0; dy < K; dy++)
-#pragma unroll
-        for (int dx = 0; dx < K; dx++) cand[dy][dx] = 0xffffffffu;
     unsigned m[6];                                     // rank still to be found, minus one, bit-sliced: starts at (K * K - 1) / 2
 #pragma unroll
     for (int b = 0; b < 6; b++) m[b] = (((K * K - 1) / 2) >> b) & 1 ? 0xffffffffu : 0u;
     const unsigned long long* rows = s_pl + row + 3 - R;
+    if (nlive == 1) { bs_round<K, true, true>(rows, 7, sh, cand, m, s_res + threadIdx.x); return; }
+    bs_round<K, true, false>(rows, 7, sh, cand, m, s_res + threadIdx.x);
 #pragma unroll 1
-    for (int i = 0; i < nlive; i++) {
-        const int p = (int)((live_list >> (4 * i)) & 7u);                  // block-uniform
-        unsigned W[K];
-#pragma unroll
-        for (int dy = 0; dy < K; dy++) {
-            const unsigned long long v = rows[p * M_ROWS + dy];
-            W[dy] = __builtin_amdgcn_alignbit((unsigned)(v >> 32), (unsigned)v, (unsigned)sh);
-        }
-        unsigned v0[K], v1[K], v2[K];
-#pragma unroll
-        for (int dx = 0; dx < K; dx++) {
-            unsigned t[K];
-#pragma unroll
-            for (int dy = 0; dy < K; dy++) t[dy] = cand[dy][dx] & W[dy];
-            if (K == 7) bs_col7(reinterpret_cast<const unsigned (&)[7]>(t), v0[dx], v1[dx], v2[dx]);
-            else bs_col5(reinterpret_cast<const unsigned (&)[5]>(t), v0[dx], v1[dx], v2[dx]);
-            // onto the output's column: the element at offset dx of the window that starts at column a sits at column a + dx
-            if (dx) { v0[dx] >>= dx; v1[dx] >>= dx; v2[dx] >>= dx; }
-        }
-        unsigned c[6];
-        if (K == 7) bs_sum7(reinterpret_cast<const unsigned (&)[7]>(v0), reinterpret_cast<const unsigned (&)[7]>(v1), reinterpret_cast<const unsigned (&)[7]>(v2), c);
-        else bs_sum5(reinterpret_cast<const unsigned (&)[5]>(v0), reinterpret_cast<const unsigned (&)[5]>(v1), reinterpret_cast<const unsigned (&)[5]>(v2), c);
-        // m - c: the final borrow says c > m, i.e. at least `rank` candidates have a 1: the median's bit is 1
-        unsigned dif[6], bor = 0u;
-#pragma unroll
-        for (int b = 0; b < 6; b++) {
-            dif[b] = bitop3<0x96>(m[b], c[b], bor);
-            bor = bitop3<0x8E>(m[b], c[b], bor);                            // (~m & (c | bor)) | (c & bor)
-        }
-        const unsigned ge = bor;
-        s_res[i * 256 + threadIdx.x] = ge;
-#pragma unroll
-        for (int b = 0; b < 6; b++) m[b] = bitop3<0xCA>(ge, m[b], dif[b]);   // ge ? m : m - c -- bit 0: the c candidates with a 1 are larger than the median
-#pragma unroll
-        for (int dx = 0; dx < K; dx++) {
-            const unsigned gsh = ge << dx;
-#pragma unroll
-            for (int dy = 0; dy < K; dy++) cand[dy][dx] = bitop3<0x90>(cand[dy][dx], W[dy], gsh);      // cand & ~(plane ^ bit)
-        }
-    }
+    for (int i = 1; i + 1 < nlive; i++)
+        bs_round<K, false, false>(rows, (int)((live_list >> (4 * i)) & 7u), sh, cand, m, s_res + i * 256 + threadIdx.x);
+    bs_round<K, false, true>(rows, (int)((live_list >> (4 * (nlive - 1))) & 7u), sh, cand, m, s_res + (nlive - 1) * 256 + threadIdx.x);
 }
 
 // the 8 result planes of a thread from the rounds' results: a plane without a round repeats the nearest live plane above it
@@ -734,7 +747,7 @@ __device__ __forceinline__ void bs_planes_to_bytes(const unsigned (&pl)[8], unsi
 // diagrams all it does is read their flags, one tile per lane (one workgroup per tile, or one tile after the other, spent
 // 0.3 us per diagram on nothing but load latencies).  The tiles it has to compute are pipelined: the source words of the next
 // one are fetched into registers while the current one is computed.
-constexpr int M_TPB = 4;
+constexpr int M_TPB = 8;
 constexpr int M_WPT = (M_ROWS * 16 + 255) / 256;     // source dwords per thread and tile
 #ifndef M_WAVES
 #define M_WAVES 3
