@@ -88,6 +88,23 @@ static int jpeg_host_decode(i2s_ctx* ctx, const std::vector<int>& list, const st
     return bad.load();
 }
 
+// The scans of progressive files that the device does not take (from dev_scans[i] on: the refinement passes and whatever follows
+// them), on the host threads, continuing on the coefficient arrays the device produced (already copied into `coef`).
+static int jpeg_host_finish(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const int* order,
+                            const std::vector<int>& dev_scans, std::vector<int16_t>& coef)
+{
+    const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
+    std::atomic<int> bad(-1);
+    rc_parallel_for((int)list.size(), [&](int n) {
+        const int i = list[n];
+        const JpegFile& f = files[i];
+        int16_t* cp[3] = {nullptr, nullptr, nullptr};
+        for (int c = 0; c < f.ncomp; c++) cp[c] = coef.data() + (ctx->h_jd[i].coef[c] - d0);
+        if (jpg_decode_scans_from(f, cp, (size_t)dev_scans[i]) != JPG_OK) bad.store(order[i]);
+    });
+    return bad.load();
+}
+
 static int jpeg_host_upload(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const std::vector<int16_t>& coef)
 {
     const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
@@ -161,8 +178,10 @@ constexpr int JE_MAX_SEGS = 1 << 16;       // restart intervals per scan handled
 // Sequential files of `list`, parallel inside each scan.  Files whose entropy-coded data hold more than stuffed bytes and RSTn
 // markers are moved to `others`.  On return the kernels have run (ctx->d_jstatus holds the verdicts; `converged` is false if
 // the iteration hit its cap: the caller decodes the list elsewhere).
+// dev_scans[i] (out): how many scans of file i the device decodes -- all of a sequential file, the scans in front of the first
+// refinement pass of a progressive one (the host threads take over from there, jpeg_host_finish).
 static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>& others, const std::vector<JpegFile>& files, const int* order,
-                         bool* converged)
+                         bool* converged, std::vector<int>& dev_scans)
 {
     *converged = true;
     std::vector<JpegHuff> tabs;
@@ -184,9 +203,18 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     size_t bo = 0;
     for (int i : list) {
         const JpegFile& f = files[i];
-        bool ok = !f.progressive;
+        bool ok = true;
         size_t bytes = 0;
-        for (const JpegScan& sc : f.scans) {
+        // a progressive file: its leading first passes (Ah = 0)
+        size_t nd = f.scans.size();
+        if (f.progressive) {
+            nd = 0;
+            while (nd < f.scans.size() && f.scans[nd].ah == 0) nd++;
+            ok = nd > 0;
+        }
+        dev_scans[i] = (int)nd;
+        for (size_t si = 0; si < nd; si++) {
+            const JpegScan& sc = f.scans[si];
             if (!ok) break;
             const bool single = sc.ns == 1;
             const JpegComp& c0 = f.c[sc.ci[0]];
@@ -199,11 +227,13 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
         if (!ok || bo + bytes >= (1ull << 31)) { others.push_back(i); continue; }
         kept.push_back(i);
         seg_first.push_back(segs.size());
-        for (const JpegScan& sc : f.scans) {
+        for (size_t si = 0; si < nd; si++) {
+            const JpegScan& sc = f.scans[si];
             JeScan js;
             memset(&js, 0, sizeof(js));
             const bool single = sc.ns == 1;
             js.ns = sc.ns; js.bpm = 0;
+            js.kind = !f.progressive ? 0 : (sc.ss == 0 ? 1 : 2); js.ss = sc.ss; js.se = sc.se; js.al = f.progressive ? sc.al : 0;
             for (int k = 0; k < sc.ns; k++) {
                 const JpegComp& jc = f.c[sc.ci[k]];
                 js.coef[k] = const_cast<int16_t*>(ctx->h_jd[i].coef[sc.ci[k]]);
@@ -322,7 +352,9 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     struct Span { i2s_ctx* c; double t; float w; ~Span() { c->jpeg_ms[1] += (float)(now_ms() - t) - (c->jpeg_ms[2] - w); } } span{ctx, t_in, w_in};
     I2S_HIP(hipMemsetAsync(ctx->d_jpg, 0, ncoef, ctx->stream));                      // coefficients start at zero
     I2S_HIP(hipMemsetAsync(ctx->d_jstatus, 0, (size_t)nb * sizeof(int), ctx->stream));
-    for (int i = 0; i < nb; i++) (mode == 0 ? host : (files[i].progressive ? (mode == 1 ? host : lanes) : par)).push_back(i);
+    // mode 1: sequential files and the first passes of progressive files on the device (parallel inside every scan), the
+    // refinement passes of the latter afterwards on the host threads; mode 2: progressive files one lane per file on the device
+    for (int i = 0; i < nb; i++) (mode == 0 ? host : (files[i].progressive && mode == 2 ? lanes : par)).push_back(i);
     // the host threads start on their files at once and run beside the device's
     int host_bad = -1;
     std::thread host_job;
@@ -332,11 +364,37 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     if (!host.empty()) host_job = std::thread([&]() { host_bad = jpeg_host_decode(ctx, host, files, order, coef); });
     bool converged = true;
     std::vector<int>& rest = mode == 2 ? lanes : late;          // files the parallel decoder hands back
-    int rc = jpeg_parallel(ctx, par, rest, files, order, &converged);
+    std::vector<int> dev_scans((size_t)nb, 0);
+    int rc = jpeg_parallel(ctx, par, rest, files, order, &converged, dev_scans);
     if (rc) return rc;
     if (!converged) {
         rest.insert(rest.end(), par.begin(), par.end());
         par.clear();
+        // what the unfinished iteration may have left of them is wiped: the serial decoders start from zeroed coefficients
+        I2S_HIP(hipMemsetAsync(ctx->d_jpg, 0, ncoef, ctx->stream));
+    }
+    // progressive files the device has started: their coefficient arrays come to the host, which runs the remaining passes
+    std::vector<int> prog;
+    for (int i : par) if (files[i].progressive && (size_t)dev_scans[i] < files[i].scans.size()) prog.push_back(i);
+    if (!prog.empty()) {
+        need_coef();
+        const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
+        for (int i : prog)
+            for (int c = 0; c < files[i].ncomp; c++) {
+                const size_t off = (size_t)(ctx->h_jd[i].coef[c] - d0);
+                I2S_HIP(hipMemcpyAsync(coef.data() + off, ctx->d_jpg + off * sizeof(int16_t), (size_t)files[i].c[c].bw * files[i].c[c].bh * 64 * sizeof(int16_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+            }
+        I2S_HIP(hipMemcpyAsync(ctx->h_jstatus, ctx->d_jstatus, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        const double t0 = now_ms();
+        I2S_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->jpeg_ms[2] += (float)(now_ms() - t0);
+        for (int i : prog)
+            if (ctx->h_jstatus[i] != JPG_OK) return jpeg_bad(ctx, order[i]);
+        const int pb = jpeg_host_finish(ctx, prog, files, order, dev_scans, coef);
+        if (pb >= 0) return jpeg_bad(ctx, pb);
+        rc = jpeg_host_upload(ctx, prog, files, coef);
+        if (rc) return rc;
     }
     std::vector<uint8_t> bytes;
     rc = jpeg_lanes(ctx, lanes, files, jpeg, len, order, bytes);

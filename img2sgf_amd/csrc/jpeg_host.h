@@ -493,11 +493,12 @@ static inline size_t jpg_destuff(const uint8_t* d, size_t n, uint8_t* out)
     return o;
 }
 
-// Host path: all scans of a parsed file, in file order.
-static int jpg_decode_scan(const JpegFile& f, int16_t* const coef[3])
+// Host path: the scans of a parsed file from scan `first` on, in file order (first = 0: the whole file, onto zeroed coefficients).
+static int jpg_decode_scans_from(const JpegFile& f, int16_t* const coef[3], size_t first)
 {
     const JpegFrameView fv = jpg_frame_view(f);
-    for (const JpegScan& sc : f.scans) {
+    for (size_t si = first; si < f.scans.size(); si++) {
+        const JpegScan& sc = f.scans[si];
         JpegScanView v;
         v.ns = sc.ns; v.ss = sc.ss; v.se = sc.se; v.ah = sc.ah; v.al = sc.al; v.dri = sc.dri;
         for (int k = 0; k < 3; k++) { v.ci[k] = sc.ci[k]; v.td[k] = sc.td[k]; v.ta[k] = sc.ta[k]; }
@@ -508,5 +509,6 @@ static int jpg_decode_scan(const JpegFile& f, int16_t* const coef[3])
     }
     return JPG_OK;
 }
+static int jpg_decode_scan(const JpegFile& f, int16_t* const coef[3]) { return jpg_decode_scans_from(f, coef, 0); }
 
 }  // namespace i2s

@@ -22,7 +22,10 @@
 //
 // The verdict matches jpg_decode_scan_view (jpeg_host.h): a segment is good iff the true parse completes at least the blocks
 // its restart interval holds before it runs out of bits (what follows them is ignored, as the serial decoder never looks at
-// it).  Progressive files keep the serial decoder (host threads, or k_jpeg_huffman).
+// it).  Progressive files (round 3): the scans in front of the first refinement pass -- DC first passes and AC first passes, the
+// same resynchronising code words with an end-of-band run on top -- are decoded here as well; the refinement passes, whose parse
+// depends on which coefficients of a block are already non-zero, stay with the serial decoder on the host threads, which takes
+// over the coefficient arrays where the device left them (api_jpeg.h).
 #pragma once
 #include "i2s_types.h"
 #include "jpeg_host.h"
@@ -50,6 +53,10 @@ struct JeScan {
     int ns, bpm, nx;             // components in the scan, blocks per MCU, MCUs per row
     int seg0, nseg;              // its segments in segs[]
     uint32_t sub0, nsub;         // its subsequences (sub0 is a multiple of JE_BLOCK)
+    // 0: a sequential scan.  Progressive files, first passes only (Ah = 0; a refinement pass does not resynchronise, see below):
+    // 1: DC scan -- every code word is a DC difference and completes its block; 2: AC scan of ONE component, band ss .. se -- a
+    // block starts at zigzag index ss, EOBn ends the block AND the next 2^n + bits - 1 ones.  Values are scaled by 2^al.
+    int kind, ss, se, al;
 };
 
 // blocks completed, sum of the DC differences per component slot, blocks completed when the first impossible code word was met (-1: none)
@@ -133,20 +140,23 @@ __device__ __forceinline__ unsigned long long je_decode(const JeShared& sh, cons
 {
     if (state == JE_DEAD) return JE_DEAD;
     const JeScan& sc = sh.sc;
+    const int kind = sc.kind, z0 = kind == 2 ? sc.ss : 0, zend = kind == 2 ? sc.se : 63, al = sc.al;
     uint32_t p = (uint32_t)(state >> 16);
     int z = (int)(state >> 8) & 255, u = (int)state & 255;
     int k = sh.uk[u];
     int16_t* blk = nullptr;
     uint32_t mx = 0, my = 0;
-    if (WRITE) {
+    auto place = [&]() {
         const uint32_t m = q / (uint32_t)sc.bpm;
         my = m / (uint32_t)sc.nx; mx = m - my * (uint32_t)sc.nx;
         blk = sc.coef[k] + ((size_t)(my * sc.vk[k] + sh.uby[u]) * sc.bw[k] + (size_t)(mx * sc.hk[k] + sh.ubx[u])) * 64;
-    }
+    };
+    if (WRITE) place();
     while (p < end) {
         if (WRITE && q >= quota) break;                         // the interval's blocks are complete: what follows is not looked at
         const uint32_t v = je_peek32(slot, p - bit0);
-        const JpegHuff& h = *reinterpret_cast<const JpegHuff*>(sh.tab[z == 0 ? k : 3 + k]);
+        const bool dc = kind != 2 && z == 0;
+        const JpegHuff& h = *reinterpret_cast<const JpegHuff*>(sh.tab[dc ? k : 3 + k]);
         // A guessed parse meets code words no encoder writes (no such code, a DC category beyond 11, a run past the end of the
         // block).  It must carry on all the same -- by any fixed rule -- to fall into step with the true parse; the true parse
         // meeting one means a corrupt file: the first is noted and k_je_scan judges whether it lies inside the interval's blocks.
@@ -154,12 +164,13 @@ __device__ __forceinline__ unsigned long long je_decode(const JeShared& sh, cons
         int sym = je_symbol(h, v, len);
         bool bad = false;
         if (sym < 0) { sym = 0; len = 16; bad = true; }
-        bool done = false;
+        bool done = false, eob = false;
         int s, zi = z;
-        if (z == 0) {
+        if (dc) {
             bad |= sym > 11;
             s = sym & 15;
             z = 1;
+            done = kind == 1;                                   // a progressive DC scan: the block is complete
         } else {
             const int r = sym >> 4;
             s = sym & 15;
@@ -168,30 +179,37 @@ __device__ __forceinline__ unsigned long long je_decode(const JeShared& sh, cons
                 z = zi + 1;
                 if (zi > 63) { bad = true; zi = 64; z = 64; }
             } else if (r == 15) z += 16;
-            else z = 64;
-            done = z >= 64;
+            else {
+                z = 64;
+                if (kind == 2) { eob = true; s = r; }           // EOBn: r more bits say how long the run of finished blocks is
+            }
+            done = z > zend;
         }
         if (bad && acc.bad_at < 0) acc.bad_at = acc.cnt;
         if (p + len + s > L) return JE_DEAD;                    // the code word is cut off by the end of the data
         p += len + s;
         int val = 0;
+        uint32_t run = 1;                                       // blocks this code word completes
         if (s) {
             const int bits = (int)((v << len) >> (32 - s));
             val = bits < (1 << (s - 1)) ? bits - (1 << s) + 1 : bits;
+            if (eob) run = (1u << s) + (uint32_t)bits;
         }
-        if (zi == 0) {
+        if (dc) {
             acc.dc[0] += k == 0 ? val : 0; acc.dc[1] += k == 1 ? val : 0; acc.dc[2] += k == 2 ? val : 0;
-            if (WRITE) blk[0] = (int16_t)(k == 0 ? acc.dc[0] : (k == 1 ? acc.dc[1] : acc.dc[2]));
-        } else if (WRITE && s && zi < 64) blk[sh.zz[zi]] = (int16_t)val;
+            if (WRITE) blk[0] = (int16_t)((k == 0 ? acc.dc[0] : (k == 1 ? acc.dc[1] : acc.dc[2])) * (1 << al));
+        } else if (WRITE && !eob && s && zi < 64) blk[sh.zz[zi]] = (int16_t)(val * (1 << al));
         if (done) {
-            z = 0;
-            acc.cnt++;
+            z = z0;
+            acc.cnt += (int)run;
             if (++u == sc.bpm) u = 0;
             k = sh.uk[u];
             if (WRITE) {
-                q++;
-                if (u == 0 && ++mx == (uint32_t)sc.nx) { mx = 0; my++; }
-                blk = sc.coef[k] + ((size_t)(my * sc.vk[k] + sh.uby[u]) * sc.bw[k] + (size_t)(mx * sc.hk[k] + sh.ubx[u])) * 64;
+                q += run;
+                if (run == 1) {
+                    if (u == 0 && ++mx == (uint32_t)sc.nx) { mx = 0; my++; }
+                    blk = sc.coef[k] + ((size_t)(my * sc.vk[k] + sh.uby[u]) * sc.bw[k] + (size_t)(mx * sc.hk[k] + sh.ubx[u])) * 64;
+                } else place();                                 // (only in single-component scans: u stays 0)
             }
         }
     }
@@ -228,7 +246,8 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_sync(const JeScan* __restrict__
     if (!sh.any) return;                                        // nothing of this workgroup changed in the round before
     je_stage(sh, sc, tabs, blob, off_dw, active);
     if (!active) return;
-    const unsigned long long entry = first ? 0ull : (round == 0 ? je_pack(j * JE_SUB_BITS, 0, 0) : E[g]);
+    const int z0 = sc.kind == 2 ? sc.ss : 0;                    // zigzag index at the start of a block
+    const unsigned long long entry = first ? je_pack(0, z0, 0) : (round == 0 ? je_pack(j * JE_SUB_BITS, z0, 0) : E[g]);
     JeAcc acc = {0, {0, 0, 0}, -1};
     const uint32_t end = last ? L : (j + 1) * JE_SUB_BITS;
     const unsigned long long exit = je_decode<false>(sh, sh.slot + threadIdx.x * JE_SLOT, j * JE_SUB_BITS, end, L, entry, acc, 0, 0);
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_write(const JeScan* __restrict_
     }
     je_stage(sh, sc, tabs, blob, off_dw, active);
     if (!active) return;
-    const unsigned long long entry = j == 0 ? 0ull : E[g];
+    const unsigned long long entry = j == 0 ? je_pack(0, sc.kind == 2 ? sc.ss : 0, 0) : E[g];
     JeAcc acc = base[g];
     if ((uint32_t)acc.cnt >= nblk) return;
     const bool last = (j + 1) * JE_SUB_BITS >= L;
