@@ -24,6 +24,18 @@ extern "C" int i2s_jpeg_info(const uint8_t* data, size_t len, int* w, int* h, in
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+int JpegCoefHost::reserve(i2s_ctx* ctx, size_t count)
+{
+    if (count <= n) return I2S_OK;
+    I2S_HIP(hipStreamSynchronize(ctx->stream));
+    if (p) I2S_HIP(hipHostFree(p));
+    p = nullptr; n = 0;
+    const size_t want = count + count / 4;
+    I2S_HIP(hipHostMalloc(&p, want * sizeof(int16_t)));
+    n = want;
+    return I2S_OK;
+}
+
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // fn(i) for i in [0, n) on up to 16 host threads (the calling one included).  fn must not throw.
@@ -71,7 +83,7 @@ static int jpeg_bad(i2s_ctx* ctx, int k)
 
 // The serial decoder on the host threads for `list` (no HIP calls: it may run beside the device work); -1 or the input index
 // of a corrupt file.  coef must already hold ncoef bytes.
-static int jpeg_host_decode(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const int* order, std::vector<int16_t>& coef)
+static int jpeg_host_decode(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const int* order, JpegCoefHost& coef)
 {
     const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
     std::atomic<int> bad(-1);
@@ -91,7 +103,7 @@ static int jpeg_host_decode(i2s_ctx* ctx, const std::vector<int>& list, const st
 // The scans of progressive files that the device does not take (from dev_scans[i] on: the refinement passes and whatever follows
 // them), on the host threads, continuing on the coefficient arrays the device produced (already copied into `coef`).
 static int jpeg_host_finish(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const int* order,
-                            const std::vector<int>& dev_scans, std::vector<int16_t>& coef)
+                            const std::vector<int>& dev_scans, JpegCoefHost& coef)
 {
     const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
     std::atomic<int> bad(-1);
@@ -105,7 +117,7 @@ static int jpeg_host_finish(i2s_ctx* ctx, const std::vector<int>& list, const st
     return bad.load();
 }
 
-static int jpeg_host_upload(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, const std::vector<int16_t>& coef)
+static int jpeg_host_upload(i2s_ctx* ctx, const std::vector<int>& list, const std::vector<JpegFile>& files, JpegCoefHost& coef)
 {
     const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
     for (int i : list)
@@ -343,7 +355,7 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
 }
 
 static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& files, const uint8_t* const* jpeg, const size_t* len, const int* order,
-                             int mode, size_t ncoef, std::vector<int16_t>& coef)
+                             int mode, size_t ncoef, JpegCoefHost& coef)
 {
     std::vector<int> par, host, lanes, late;
     ctx->je_rounds = 0;
@@ -359,8 +371,11 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     int host_bad = -1;
     std::thread host_job;
     struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{host_job};
-    auto need_coef = [&]() { if (coef.size() < ncoef / sizeof(int16_t)) coef.resize(ncoef / sizeof(int16_t)); };     // the host copy: 15 x the file bytes
+    // the host copy of coefficient arrays (15 x the file bytes): pinned -- the arrays of progressive files cross the bus twice
+    int coef_rc = I2S_OK;
+    auto need_coef = [&]() { if (coef_rc == I2S_OK) coef_rc = coef.reserve(ctx, ncoef / sizeof(int16_t)); };
     if (!host.empty()) need_coef();
+    if (coef_rc) return coef_rc;
     if (!host.empty()) host_job = std::thread([&]() { host_bad = jpeg_host_decode(ctx, host, files, order, coef); });
     bool converged = true;
     std::vector<int>& rest = mode == 2 ? lanes : late;          // files the parallel decoder hands back
@@ -378,6 +393,7 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     for (int i : par) if (files[i].progressive && (size_t)dev_scans[i] < files[i].scans.size()) prog.push_back(i);
     if (!prog.empty()) {
         need_coef();
+        if (coef_rc) return coef_rc;
         const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
         for (int i : prog)
             for (int c = 0; c < files[i].ncomp; c++) {
@@ -400,7 +416,11 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     rc = jpeg_lanes(ctx, lanes, files, jpeg, len, order, bytes);
     if (rc) return rc;
     if (host_job.joinable()) host_job.join();
-    if (host_bad < 0 && !late.empty()) { need_coef(); host_bad = jpeg_host_decode(ctx, late, files, order, coef); }
+    if (host_bad < 0 && !late.empty()) {
+        need_coef();
+        if (coef_rc) return coef_rc;
+        host_bad = jpeg_host_decode(ctx, late, files, order, coef);
+    }
     if (host_bad >= 0) return jpeg_bad(ctx, host_bad);
     rc = jpeg_host_upload(ctx, host, files, coef);
     if (rc) return rc;
@@ -479,7 +499,7 @@ extern "C" int i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* 
     pd.inputs_on_device = 1;
     pd.schedule = 0;
     float timing[5] = {0, 0, 0, 0, 0};
-    std::vector<int16_t> coef;
+    JpegCoefHost& coef = ctx->h_coef;
     std::vector<i2s_board> pb(ctx->max_batch);
     std::vector<i2s_result> pf(full ? ctx->max_batch : 0);
     std::vector<i2s_xform> pxf(xf ? ctx->max_batch : 0);

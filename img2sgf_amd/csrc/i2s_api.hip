@@ -36,6 +36,15 @@ constexpr int HYST_MAX_PASSES = 4096;
 constexpr int RAD_GX = 32;
 }  // namespace
 
+// host copy of JPEG coefficient arrays (progressive files): pinned, owned by the context, grown on demand
+struct JpegCoefHost {
+    int16_t* p = nullptr;
+    size_t n = 0;
+    int16_t* data() const { return p; }
+    size_t size() const { return n; }
+    int reserve(struct i2s_ctx* ctx, size_t count);
+};
+
 struct i2s_ctx {
     int device = 0, max_batch = 0, max_w = 0, max_h = 0;
     Geo geo{};
@@ -71,6 +80,7 @@ struct i2s_ctx {
     uint32_t* h_jflag = nullptr; // pinned
     uint8_t* h_jblob = nullptr;  // pinned: the destuffed entropy-coded bytes of a pass (grown on demand)
     size_t jblob_bytes = 0;
+    JpegCoefHost h_coef;         // pinned: coefficient arrays of progressive files on their way to / from the host decoder
     int je_rounds = 0;           // rounds k_je_sync took in the last pass
     int je_max_rounds = 2048;    // beyond this a pass is handed to the serial decoder (i2s_jpeg_set_max_rounds)
     float jpeg_ms[4] = {0, 0, 0, 0};     // last i2s_detect_jpeg_batch: parsing | entropy stage, host work | entropy stage, waiting for the device | whole call
@@ -167,7 +177,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
                    ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
     for (void* q : dev) if (q) (void)hipFree(q);
-    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob};
+    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob, ctx->h_coef.p};
     for (void* q : host) if (q) (void)hipHostFree(q);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i <= I2S_NSEG; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
