@@ -131,11 +131,13 @@ typedef struct i2s_params {
      * images sorted by area, so that a pass's tile grids (sized for its largest image) are not mostly empty; results are
      * returned in input order.  The "last pass" the fetch / classify calls refer to is then the pass of the largest images. */
     int32_t schedule;
-    /* i2s_detect_jpeg_batch, where the Huffman decoding runs.  1 (default): sequential files on the device, parallel inside
-     * every scan (csrc/k_jpeg_entropy.h); progressive files, and files whose entropy-coded data hold anything but stuffed
-     * FF00 bytes and RSTn markers, on host threads meanwhile.  0: every file on host threads (round 1's path).  2: as 1, but
-     * the files the parallel decoder does not take run on the device too, one lane per file (slow: DESIGN.md 6c).  The three
-     * give the same coefficients, bit for bit, and refuse the same files. */
+    /* i2s_detect_jpeg_batch, where the Huffman decoding runs.  1 (default): sequential files, and the scans of progressive files
+     * in front of their first refinement pass (DC and AC first passes), on the device, parallel inside every scan
+     * (csrc/k_jpeg_entropy.h); the remaining passes of progressive files afterwards on host threads, and files whose
+     * entropy-coded data hold anything but stuffed FF00 bytes and RSTn markers wholly on host threads.  0: every file on host
+     * threads (round 1's path).  2: sequential files as 1, progressive files and whatever the parallel decoder does not take on
+     * the device too, one lane per file (slow: DESIGN.md 7a).  The three give the same coefficients, bit for bit, and refuse the
+     * same files. */
     int32_t jpeg_entropy_device;
 } i2s_params;
 
