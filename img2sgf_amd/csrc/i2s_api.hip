@@ -548,9 +548,6 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             I2S_HIP(hipMemcpyAsync(ctx->d_sink + dst[0], ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToDevice, st));
         else if (ctx->d_sink) for (int i = 0; i < nb; i++)
             I2S_HIP(hipMemcpyAsync(ctx->d_sink + dst[i], ctx->d_boards + i, sizeof(i2s_board), hipMemcpyDeviceToDevice, st));
-        if (full && dense) I2S_HIP(hipMemcpyAsync(full + dst[0], ctx->d_res, nb * sizeof(i2s_result), hipMemcpyDeviceToHost, st));
-        else if (full) for (int i = 0; i < nb; i++)
-            I2S_HIP(hipMemcpyAsync(full + dst[i], ctx->d_res + i, sizeof(i2s_result), hipMemcpyDeviceToHost, st));
         I2S_HIP(hipStreamSynchronize(st));
         I2S_HIP(hipGetLastError());
         bool converged = true;
@@ -569,6 +566,21 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         // hysteresis had not reached its fixed point: redo this device pass with more plain launches
     }
     for (int i = 0; i < nb; i++) boards[dst[i]] = ctx->h_boards[i];
+    if (full) {
+        // The full record is 233 KB, nearly all of it the circle arrays' capacity: only what is in use crosses the bus -- the part
+        // in front of the circles, n_circles circles, n_circles kept flags, the two boards behind them (the board record, already
+        // on the host, says how many circles there are).  Array entries beyond the counts are left as the caller had them.
+        for (int i = 0; i < nb; i++) {
+            const size_t n = ctx->h_boards[i].n_circles;
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(ctx->d_res + i);
+            uint8_t* out = reinterpret_cast<uint8_t*>(full + dst[i]);
+            I2S_HIP(hipMemcpyAsync(out, src, offsetof(i2s_result, circles) + n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (n) I2S_HIP(hipMemcpyAsync(out + offsetof(i2s_result, circle_kept), src + offsetof(i2s_result, circle_kept), n, hipMemcpyDeviceToHost, st));
+            I2S_HIP(hipMemcpyAsync(out + offsetof(i2s_result, detected), src + offsetof(i2s_result, detected),
+                                   sizeof(i2s_result) - offsetof(i2s_result, detected), hipMemcpyDeviceToHost, st));
+        }
+        I2S_HIP(hipStreamSynchronize(st));
+    }
     float ms;
     for (int i = 0; i < 4; i++) {
         I2S_HIP(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));

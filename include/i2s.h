@@ -156,7 +156,9 @@ typedef struct i2s_board {
     uint8_t pad[8];
 } i2s_board;
 
-/* Full per-image record: every value the reference leaves in its globals for the GUI. */
+/* Full per-image record: every value the reference leaves in its globals for the GUI.  Array entries beyond their counts
+ * (circles[n_circles ..], circle_kept[n_circles ..], hlines[n_hlines ..] ...) are unspecified: a detect call copies only the
+ * used part of the circle arrays to the host (the record's capacity is 233 KB, a diagram uses about 20). */
 typedef struct i2s_result {
     int32_t status;
     int32_t line_threshold;
