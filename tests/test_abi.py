@@ -53,3 +53,23 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|libi2s_oracle|oracle/", txt, re.M), os.path.join(dp, f)
+
+
+def test_comm_errors_have_text():
+    """i2s_comm_create with bad arguments is refused before anything collective happens, and a failure that has no communicator
+    to hang its text on (no device here; librccl missing; RCCL error) is reported through i2s_comm_last_error(NULL)."""
+    import ctypes as C
+    from img2sgf_amd import _lib
+    lib = _lib.load()
+    comm = C.c_void_p()
+    idb = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    assert lib.dll.i2s_comm_create(C.byref(comm), 0, idb, 0, 0, 4) == -1            # world < 1: I2S_E_INVALID
+    assert lib.dll.i2s_comm_create(C.byref(comm), 0, idb, 2, 2, 4) == -1            # rank >= world
+    assert not comm.value
+    ctx = C.c_void_p()
+    if lib.dll.i2s_create(C.byref(ctx), 0, 1, 64, 64) == 0:                         # a GPU is here: a made-up communicator id must not
+        lib.dll.i2s_destroy(ctx)                                                    # reach ncclCommInitRank (the GPU tests cover the real thing)
+        return
+    rc = lib.dll.i2s_comm_create(C.byref(comm), 0, idb, 1, 0, 4)
+    assert rc in (-2, -3)                                                           # I2S_E_NO_DEVICE / I2S_E_HIP
+    assert len(lib.dll.i2s_comm_last_error(None).decode()) > 0
