@@ -245,23 +245,32 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        int ns = 0;
-        if (ready) {
+    // the stones in the reference's order (j over hsize, k over vsize, :510-514): thread t looks at cell (t / vsize, t % vsize); a
+    // stone's position in the list is the number of stones in front of it (wave ballots + the waves' totals) -- the loop over the
+    // 361 cells on one lane, with its float64 window arithmetic, used to be most of this kernel's time
+    __shared__ int s_wtot[GRID_THREADS / 64];
+    int my_rank = -1, my_j = 0, my_k = 0;
+    {
+        const int ncell = ready ? hsize * vsize : 0;
+        bool stone = false;
+        if (tid < ncell) { my_j = tid / vsize; my_k = tid - my_j * vsize; stone = s_det[my_j][my_k] == I2S_STONE; }
+        const unsigned long long m = __ballot(stone);
+        const int wv = tid >> 6, ln = tid & 63;
+        if (ln == 0) s_wtot[wv] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int q = 0; q < GRID_THREADS / 64; q++) { const int c = s_wtot[q]; total += c; if (q < wv) before += c; }
+        if (stone) {
+            my_rank = before + __popcll(m & ((1ull << ln) - 1ull));
+            // average_intensity (:468-481); note x uses hspace, y uses vspace (reference quirk)
             const double hspace = R->hspace, vspace = R->vspace;
-            for (int j = 0; j < hsize; j++)
-                for (int k = 0; k < vsize; k++)
-                    if (s_det[j][k] == I2S_STONE) {
-                        // average_intensity (:468-481); note x uses hspace, y uses vspace (reference quirk)
-                        const double x = s_cmp[1][j], y = s_cmp[0][k];
-                        int xmin = (int)rint(x - hspace / 2), xmax = (int)rint(x + hspace / 2);
-                        int ymin = (int)rint(y - vspace / 2), ymax = (int)rint(y + vspace / 2);
-                        xmin = imax(0, xmin); ymin = imax(0, ymin); xmax = imin(w, xmax); ymax = imin(h, ymax);
-                        s_win[ns][0] = xmin; s_win[ns][1] = xmax; s_win[ns][2] = ymin; s_win[ns][3] = ymax;
-                        ns++;
-                    }
+            const double x = s_cmp[1][my_j], y = s_cmp[0][my_k];
+            int xmin = (int)rint(x - hspace / 2), xmax = (int)rint(x + hspace / 2);
+            int ymin = (int)rint(y - vspace / 2), ymax = (int)rint(y + vspace / 2);
+            xmin = imax(0, xmin); ymin = imax(0, ymin); xmax = imin(w, xmax); ymax = imin(h, ymax);
+            s_win[my_rank][0] = xmin; s_win[my_rank][1] = xmax; s_win[my_rank][2] = ymin; s_win[my_rank][3] = ymax;
         }
-        s_i[2] = ns;
+        if (tid == 0) s_i[2] = total;
     }
     __syncthreads();
     const int ns = s_i[2];
@@ -284,21 +293,29 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
                 const int L = imin(64, (bw + 3) >> 2);
                 const int rows_per = 64 / imax(L, 1);
                 const int ry = lane / imax(L, 1), lx = lane - ry * L;
+                // the plane is cold by now (each dword is an HBM round trip), so a lane keeps four rows' loads in flight: the
+                // address is clamped into the window and the value dropped afterwards, which keeps the loads free of branches
+                auto ld = [&](int yy, int xx) -> unsigned {
+                    const int yc = imin(yy, bh - 1);
+                    const uint8_t* p = gp0 + rowoff(ymin + yc, gpitch) + xmin + xx;
+                    const long over = (long)(p + 4 - gend);                  // > 0: the last pixels of an image used in place
+                    unsigned v4;
+                    __builtin_memcpy(&v4, over > 0 ? gend - 4 : p, 4);
+                    if (over > 0) v4 >>= 8 * (int)over;                      // over <= 3: p is a pixel of the plane
+                    const int nvalid = bw - xx;                              // >= 1
+                    if (nvalid < 4) v4 &= (1u << (8 * nvalid)) - 1u;
+                    return yy < bh ? v4 : 0u;
+                };
                 if (bw > 0 && ry < rows_per)
-                    for (int yy = ry; yy < bh; yy += rows_per) {
-                        const uint8_t* row = gp0 + rowoff(ymin + yy, gpitch) + xmin;
-                        for (int xx = 4 * lx; xx < bw; xx += 4 * L) {
-                            unsigned v4;
-                            const int nvalid = bw - xx;                       // >= 1
-                            if (row + xx + 4 <= gend) __builtin_memcpy(&v4, row + xx, 4);
-                            else {                                            // the last pixels of an image used in place
-                                v4 = 0;
-                                for (int q = 0; q < 4 && q < nvalid; q++) v4 |= (unsigned)row[xx + q] << (8 * q);
-                            }
-                            if (nvalid < 4) v4 &= (1u << (8 * nvalid)) - 1u;
-                            sum = __builtin_amdgcn_sad_u8(v4, 0u, sum);
+                    for (int xx = 4 * lx; xx < bw; xx += 4 * L)
+                        for (int yy = ry; yy < bh; yy += 4 * rows_per) {
+                            const unsigned u0 = ld(yy, xx), u1 = ld(yy + rows_per, xx);
+                            const unsigned u2 = ld(yy + 2 * rows_per, xx), u3 = ld(yy + 3 * rows_per, xx);
+                            sum = __builtin_amdgcn_sad_u8(u0, 0u, sum);
+                            sum = __builtin_amdgcn_sad_u8(u1, 0u, sum);
+                            sum = __builtin_amdgcn_sad_u8(u2, 0u, sum);
+                            sum = __builtin_amdgcn_sad_u8(u3, 0u, sum);
                         }
-                    }
             }
             for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
             if (s < ns && lane == 0) {
@@ -308,20 +325,16 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
         }
     }
     __syncthreads();
+    if (tid == 0) s_i[6] = 0;
+    __syncthreads();
+    if (my_rank >= 0) {
+        const bool black = s_br[my_rank] <= (double)gp.black_threshold;   // NaN (an empty window) compares false: white
+        s_det[my_j][my_k] = black ? I2S_BLACK : I2S_WHITE;
+        if (black) atomicAdd(&s_i[6], 1);
+    }
+    __syncthreads();
     if (tid == 0) {
-        int nblack = 0;
-        const double thr = (double)gp.black_threshold;
-        if (ready) {
-            int s = 0;
-            for (int j = 0; j < hsize; j++)
-                for (int k = 0; k < vsize; k++)
-                    if (s_det[j][k] == I2S_STONE) {
-                        const bool black = s_br[s] <= thr;
-                        s_det[j][k] = black ? I2S_BLACK : I2S_WHITE;
-                        nblack += black ? 1 : 0;
-                        s++;
-                    }
-        }
+        const int nblack = s_i[6];
         const int nwhite = ns - nblack;
         R->n_stones = ns; R->n_black = nblack; R->n_white = nwhite;
         R->board_ready = ready ? 1 : 0;
