@@ -535,7 +535,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         const int ex = cdiv(wmax, ET_W), ey = cdiv(hmax, ET_H);         // 64 x 64 tiles
         hipLaunchKernelGGL(k_erase_lines, dim3((unsigned)ex * ey * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
                            plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, ex, ey, ctx->d_tl_cnt, ctx->d_tl_idx);
-        hipLaunchKernelGGL(k_line_peaks, dim3(nb), b256, 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
+        hipLaunchKernelGGL(k_line_peaks, dim3(nb), dim3(LP_THREADS), 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
         I2S_SEG(13);
 
@@ -835,7 +835,7 @@ extern "C" int i2s_find_lines(i2s_ctx* ctx, const uint8_t* image, int w, int h, 
     e[3] = hipMemsetAsync(ctx->d_lacc, 0, (size_t)LROWS * ctx->lrow * sizeof(int), st);
     hipLaunchKernelGGL(k_erase_lines, dim3((unsigned)fx * fy), dim3(256), 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
                        plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, fx, fy, ctx->d_tl_cnt, ctx->d_tl_idx);
-    hipLaunchKernelGGL(k_line_peaks, dim3(1), dim3(256), 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
+    hipLaunchKernelGGL(k_line_peaks, dim3(1), dim3(LP_THREADS), 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
     e[4] = hipMemcpyAsync(hr, ctx->d_res, sizeof(i2s_result), hipMemcpyDeviceToHost, st);
     e[5] = hipStreamSynchronize(st);
     int out = I2S_OK;

@@ -47,30 +47,31 @@ __global__ __launch_bounds__(256) void k_concat_circles(const ImgDesc* __restric
     }
     __syncthreads();
     if (s_off[NSLOT] < 0) return;
-    for (int s = 0; s < NSLOT; s++) {
-        const int n = s_off[s + 1] - s_off[s];
+    // one flat pass over the circles of all slots (a loop over the slots costs ten load -> store -> atomic round trips in a row)
+    for (int q = threadIdx.x; q < s_off[NSLOT]; q += 256) {
+        int s = 0;
+        while (q >= s_off[s + 1]) s++;
+        const int i = q - s_off[s];
         const float* src = vcirc + (size_t)(b * NVAR + slot_variant(s)) * g.vcirc_cap * 3;
-        float* dst = &R->circles[s_off[s]][0];
-        for (int i = threadIdx.x; i < n * 3; i += 256) dst[i] = src[i];
-        // erase box of circle (s_off[s] + i): r + 2 in float32, corners rounded half-to-even (img2sgf.py:193-195)
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const float xc = src[3 * i], yc = src[3 * i + 1], r = src[3 * i + 2] + 2.0f;
-            const int bx0 = __float2int_rn(xc - r), by0 = __float2int_rn(yc - r);
-            const int bx1 = __float2int_rn(xc + r), by1 = __float2int_rn(yc + r);
-            const int lo_x = imax(imin(bx0, bx1), 0), hi_x = imin(imax(bx0, bx1), w - 1);
-            const int lo_y = imax(imin(by0, by1), 0), hi_y = imin(imax(by0, by1), h - 1);
-            if (lo_x > hi_x || lo_y > hi_y) continue;
-            TlBox rec;
-            rec.lo_x = (short)lo_x; rec.hi_x = (short)hi_x; rec.lo_y = (short)lo_y; rec.hi_y = (short)hi_y;
-            rec.mx = (short)iclamp(__float2int_rn(xc), -32768, 32767); rec.my = (short)iclamp(__float2int_rn(yc), -32768, 32767);
-            rec.idx = (unsigned short)(s_off[s] + i); rec.pad = 0;
-            for (int ty = lo_y / ET_H; ty <= hi_y / ET_H; ty++)
-                for (int tx = lo_x / ET_W; tx <= hi_x / ET_W; tx++) {
-                    const size_t t = (size_t)b * g.tiles + (size_t)ty * g.tw + tx;
-                    const int k = atomicAdd(&tl_cnt[t], 1);
-                    if (k < TL_CAP) tl_box[t * TL_CAP + k] = rec;
-                }
-        }
+        const float xc = src[3 * i], yc = src[3 * i + 1], r0 = src[3 * i + 2];
+        R->circles[q][0] = xc; R->circles[q][1] = yc; R->circles[q][2] = r0;
+        // erase box of circle q: r + 2 in float32, corners rounded half-to-even (img2sgf.py:193-195)
+        const float r = r0 + 2.0f;
+        const int bx0 = __float2int_rn(xc - r), by0 = __float2int_rn(yc - r);
+        const int bx1 = __float2int_rn(xc + r), by1 = __float2int_rn(yc + r);
+        const int lo_x = imax(imin(bx0, bx1), 0), hi_x = imin(imax(bx0, bx1), w - 1);
+        const int lo_y = imax(imin(by0, by1), 0), hi_y = imin(imax(by0, by1), h - 1);
+        if (lo_x > hi_x || lo_y > hi_y) continue;
+        TlBox rec;
+        rec.lo_x = (short)lo_x; rec.hi_x = (short)hi_x; rec.lo_y = (short)lo_y; rec.hi_y = (short)hi_y;
+        rec.mx = (short)iclamp(__float2int_rn(xc), -32768, 32767); rec.my = (short)iclamp(__float2int_rn(yc), -32768, 32767);
+        rec.idx = (unsigned short)q; rec.pad = 0;
+        for (int ty = lo_y / ET_H; ty <= hi_y / ET_H; ty++)
+            for (int tx = lo_x / ET_W; tx <= hi_x / ET_W; tx++) {
+                const size_t t = (size_t)b * g.tiles + (size_t)ty * g.tw + tx;
+                const int k = atomicAdd(&tl_cnt[t], 1);
+                if (k < TL_CAP) tl_box[t * TL_CAP + k] = rec;
+            }
     }
 }
 
@@ -272,8 +273,12 @@ __global__ __launch_bounds__(256) void k_erase_lines(const ImgDesc* __restrict__
 }
 
 // Peaks of one HoughLines call (findLocalMaximums + std::sort(hough_cmp_gt)), appended to out[] as rho.
-// Runs inside a 256-thread block; s_key is LDS scratch of I2S_MAX_LINES entries.  Returns the count (or -1
+// Runs inside an LP_THREADS block; s_key is LDS scratch of I2S_MAX_LINES entries.  Returns the count (or -1
 // on overflow) in *s_cnt after the final __syncthreads().
+// The accumulator rows are scanned along rho (consecutive lanes, consecutive counters), four counters per thread in flight; the
+// neighbours are only fetched for the few counters above the threshold.  The order in which peaks are found does not matter: they
+// are ranked by (count, OpenCV's padded index) afterwards.
+constexpr int LP_THREADS = 1024;
 __device__ __forceinline__ void lines_peaks_call(const int* __restrict__ acc /* call base: LANG rows */, int lrow, int numrho,
                                                  int numangle, int threshold, bool negate, unsigned long long* s_key,
                                                  int* s_cnt, float* __restrict__ out, int out_base)
@@ -281,24 +286,32 @@ __device__ __forceinline__ void lines_peaks_call(const int* __restrict__ acc /* 
     const int tid = threadIdx.x;
     if (tid == 0) *s_cnt = 0;
     __syncthreads();
-    for (int i = tid; i < numrho * numangle; i += 256) {
-        const int r = i / numangle, n = i - r * numangle;
-        const int a = acc[n * lrow + r];
-        if (a <= threshold) continue;
-        const int left = r > 0 ? acc[n * lrow + r - 1] : 0;
-        const int right = r < numrho - 1 ? acc[n * lrow + r + 1] : 0;
-        const int up = n > 0 ? acc[(n - 1) * lrow + r] : 0;
-        const int down = n < numangle - 1 ? acc[(n + 1) * lrow + r] : 0;
-        if (a > left && a >= right && a > up && a >= down) {
-            const int k = atomicAdd(s_cnt, 1);
-            const unsigned idx = (unsigned)((n + 1) * (numrho + 2) + r + 1);   // OpenCV's padded index: the sort tie-break
-            if (k < I2S_MAX_LINES) s_key[k] = ((unsigned long long)(0x7fffffffu - (unsigned)a) << 32) | idx;
+    for (int n = 0; n < numangle; n++) {
+        const int* row = acc + (size_t)n * lrow;
+        for (int r0 = tid; r0 < numrho; r0 += 4 * LP_THREADS) {
+            int a4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int r = r0 + q * LP_THREADS; a4[q] = row[imin(r, numrho - 1)]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = r0 + q * LP_THREADS, a = a4[q];
+                if (r >= numrho || a <= threshold) continue;
+                const int left = r > 0 ? row[r - 1] : 0;
+                const int right = r < numrho - 1 ? row[r + 1] : 0;
+                const int up = n > 0 ? row[r - lrow] : 0;
+                const int down = n < numangle - 1 ? row[r + lrow] : 0;
+                if (a > left && a >= right && a > up && a >= down) {
+                    const int k = atomicAdd(s_cnt, 1);
+                    const unsigned idx = (unsigned)((n + 1) * (numrho + 2) + r + 1);   // OpenCV's padded index: the sort tie-break
+                    if (k < I2S_MAX_LINES) s_key[k] = ((unsigned long long)(0x7fffffffu - (unsigned)a) << 32) | idx;
+                }
+            }
         }
     }
     __syncthreads();
     const int cnt = *s_cnt;
     if (cnt > I2S_MAX_LINES) { __syncthreads(); if (tid == 0) *s_cnt = -1; __syncthreads(); return; }
-    for (int i = tid; i < cnt; i += 256) {
+    for (int i = tid; i < cnt; i += LP_THREADS) {
         const unsigned long long k = s_key[i];
         int rank = 0;
         for (int j = 0; j < cnt; j++) rank += (s_key[j] < k) ? 1 : 0;   // keys are unique (idx)
@@ -312,8 +325,8 @@ __device__ __forceinline__ void lines_peaks_call(const int* __restrict__ acc /* 
 }
 
 // find_all_lines (img2sgf.py:258-265): hlines from call 0; vlines = [call 1 ; call 2 with rho negated] (245-251).
-// grid (nb), block 256.
-__global__ __launch_bounds__(256) void k_line_peaks(const ImgDesc* __restrict__ desc, const int* __restrict__ lacc, int lrow,
+// grid (nb), block LP_THREADS.
+__global__ __launch_bounds__(LP_THREADS) void k_line_peaks(const ImgDesc* __restrict__ desc, const int* __restrict__ lacc, int lrow,
                                                     HoughTrig trig, i2s_result* __restrict__ res)
 {
     __shared__ unsigned long long s_key[I2S_MAX_LINES];

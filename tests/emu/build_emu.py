@@ -3,6 +3,7 @@ the fiber-based HIP emulation in tests/emu/hip/hip_runtime.h.  ONE product heade
 assembly, DPP, buffer descriptors) by tests/emu/gfx950_ops.h (plain C with the same semantics); those machine-level paths are
 covered by the GPU tests only.  Test infrastructure only: lets the GPU-less CI
 check kernel logic against the oracle.  The product loader never looks at this file."""
+import fcntl
 import os
 import subprocess
 
@@ -16,13 +17,21 @@ def build(force=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not os.path.isdir(os.path.join(CSRC, f))] + [
         os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "gfx950_ops.h"),
         os.path.join(ROOT, "include", "i2s.h")]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+    def fresh():
+        return os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps)
+    if not force and fresh():
         return LIB
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-           "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-sign-compare",
-           "-I", HERE, "-x", "c++", os.path.join(CSRC, "i2s_api.hip"), os.path.join(HERE, "hipemu.cpp"),
-           "-o", LIB]
-    subprocess.check_call(cmd)
+    # pytest-xdist workers arrive here together: one builds (into a temporary name, renamed when complete), the others wait
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not fresh():
+            tmp = LIB + ".%d.tmp" % os.getpid()
+            cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                   "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-sign-compare",
+                   "-I", HERE, "-x", "c++", os.path.join(CSRC, "i2s_api.hip"), os.path.join(HERE, "hipemu.cpp"),
+                   "-o", tmp]
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
     return LIB
 
 
