@@ -55,7 +55,7 @@ struct i2s_ctx {
     size_t src_slot = 0;
     ImgDesc* d_desc = nullptr;
     ImgDesc* h_desc = nullptr;
-    int* d_flags = nullptr;      // [2][HYST_MAX_PASSES] "pass p changed something" per phase | [2] grid-barrier counters | [2] passes used (k_hysteresis_tail)
+    int* d_flags = nullptr;      // [2][HYST_MAX_PASSES] tiles pass p queued for pass p + 1, per phase | [2] grid-barrier counters | [2] passes used (k_hysteresis_tail)
     int* h_flags = nullptr;      // [2] passes each phase needed (-1: not converged)
     unsigned* d_cent_list = nullptr;
     int* d_counts = nullptr;     // cent_count | est_count | vcount | overflow
@@ -87,7 +87,9 @@ struct i2s_ctx {
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     TlBox* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP] box, plus centre and index of the circles that touch the tile
     int* d_weak = nullptr;       // 2 worklists (main Canny / HoughCircles' Cannys): [0] = count, then keys of tiles holding weak pixels
-    int* d_chg = nullptr;        // [2 (pass parity)][NMAP][nb][tiles] (last hysteresis pass that changed the tile + 1) << 4 | borders changed
+    int* d_chg = nullptr;        // hysteresis revisit queues: [2 (pass parity)][NMAP * nb * tiles] tile keys
+    int* d_hmark = nullptr;      // [NMAP][nb][tiles] stamp of the latest pass a tile was queued for (hy_stamp + pass + 1; only ever grows)
+    int hy_stamp = 0;            // advanced by HYST_MAX_PASSES + 2 per phase run
     int* d_mflags = nullptr;     // [nb][bands_y][bands_x] k_median57_bin: the band holds a pixel other than 0 / 255
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
@@ -175,7 +177,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_hmark, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob, ctx->h_coef.p};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -218,6 +220,8 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_tl_idx, nb * g.tiles * TL_CAP * sizeof(TlBox)));
     I2S_HIP(hipMalloc(&ctx->d_weak, 2 * (nb * NMAP * g.tiles + 1) * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_chg, 2 * nb * NMAP * g.tiles * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_hmark, nb * NMAP * g.tiles * sizeof(int)));
+    I2S_HIP(hipMemset(ctx->d_hmark, 0, nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_mflags, nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
     ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
@@ -362,12 +366,18 @@ static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
     uint8_t* maps = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
     uint8_t* edges = phase == 0 ? plane_ptr(ctx, I2S_PLANE_EDGES) : (uint8_t*)nullptr;
     const int k = ctx->hyst_k[phase];
-    const size_t chg_half = (size_t)ctx->max_batch * NMAP * ctx->geo.tiles;
+    const size_t queue_half = (size_t)ctx->max_batch * NMAP * ctx->geo.tiles;
+    if (ctx->hy_stamp > 0x7fffffff - 4 * (HYST_MAX_PASSES + 2)) {         // once in ~250 000 calls: start the stamps over
+        I2S_HIP(hipMemsetAsync(ctx->d_hmark, 0, queue_half * sizeof(int), ctx->stream));
+        ctx->hy_stamp = 0;
+    }
+    const int stamp_base = ctx->hy_stamp;
+    ctx->hy_stamp += HYST_MAX_PASSES + 2;
     for (int pass = 0; pass < k; pass++)
         hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, pass,
-                           worklist(ctx, phase), ctx->d_chg, chg_half);
+                           worklist(ctx, phase), ctx->d_chg, queue_half, ctx->d_hmark, stamp_base);
     hipLaunchKernelGGL(k_hysteresis_tail, dim3(HY_TAIL_BLOCKS), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, k,
-                       HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, chg_half, counter, info);
+                       HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, queue_half, ctx->d_hmark, stamp_base, counter, info);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
@@ -441,7 +451,6 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, (2 * HYST_MAX_PASSES + 4) * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 0), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 1), 0, sizeof(int), st));
-        I2S_HIP(hipMemsetAsync(ctx->d_chg, 0, (size_t)2 * ctx->max_batch * NMAP * g.tiles * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_mflags, 0, (size_t)nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);

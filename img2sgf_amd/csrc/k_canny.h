@@ -125,10 +125,15 @@ __global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict
 // (((M + S) ^ M) & M, M = W | S, in both bit orders).  The tile reaches its local fixed point in as many steps as its
 // longest chain spans ROWS, with no workgroup barrier and no LDS -- scans of photographs, whose contours wander across
 // whole tiles, spent a third of their GPU time in the previous byte-per-thread version (up to 300 us per launch).
-// The host launches passes back to back; a pass returns at once when the previous pass changed nothing anywhere
-// (flags[pass-1] == 0), and from pass 1 on a tile is revisited only if it or one of its 8 neighbours changed in the previous
-// pass on a border that faces it (chg[tile] = (index of the last pass that changed it + 1) << 4 | borders it changed).  The result is the unique fixed point, independent of
-// scheduling and of the list order.
+// The host launches passes back to back.  Pass 0 walks the worklist of the Sobel / NMS kernel (tiles that hold weak pixels); a tile
+// leaves its visit at its local fixed point, so it has to be looked at again only if its APRON changes -- a tile that promotes
+// pixels on a border queues the neighbours that border faces (the bottom row: the tile below; the bottom row AND the right
+// column, i.e. the corner pixel: also the one below right ...) for the next pass: queue[(pass + 1) & 1], flags[pass] = its
+// length, marks[tile] = stamp of the latest pass the tile is queued for (atomicMax: a tile enters a queue once).  Pass p >= 1
+// walks queue[p & 1] only, and returns at once when it is empty (flags[p - 1] == 0): the fixed point.  The result is the unique
+// fixed point, independent of scheduling and of the list order.  (Round 3's first version kept a per-tile "borders changed"
+// record that every pass looked up for all nine neighbours of every worklist tile: on noisy scans, where every tile is on the
+// worklist, that scan alone was 25-35 us per pass and 256 images.)
 // maps points at map 0; map m of image b at (m * nb + b) * slot.  `edges` (non-null for the main Canny's phase, whose worklist
 // holds map-0 tiles only) receives 255 / 0 for every rewritten dword: together with the NMS kernel's output that is the edge
 // image of img2sgf.py:162.  grid (HY_BLOCKS), block 256 = 4 independent wavefronts.
@@ -149,42 +154,22 @@ __device__ __forceinline__ unsigned long long hy_fill_up(unsigned long long S, u
 // one pass over this workgroup's share of the worklist (entries first, first + stride, ...; one wavefront per entry)
 __device__ __forceinline__ void hysteresis_pass(const ImgDesc* __restrict__ desc, const Geo& g, uint8_t* __restrict__ maps,
                                                 uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
-                                                const int* __restrict__ wl, int* __restrict__ chg2, size_t chg_half)
+                                                const int* __restrict__ wl, int* __restrict__ queues, size_t queue_half,
+                                                int* __restrict__ marks, int stamp_base)
 {
-    // two copies of the per-tile record, by pass parity: a pass READS what the previous pass wrote and WRITES its own copy, so a
-    // tile that changes again in this pass (perhaps in its interior only) cannot wipe out the border bits its neighbours have
-    // yet to look at
-    const int* chg_prev = chg2 + (size_t)((pass + 1) & 1) * chg_half;
-    int* chg = chg2 + (size_t)(pass & 1) * chg_half;
-    const int nwl = wl[0];
+    const int* src = pass == 0 ? wl + 1 : queues + (size_t)(pass & 1) * queue_half;
+    int* dst = queues + (size_t)((pass + 1) & 1) * queue_half;
+    const int nwl = pass == 0 ? wl[0] : load_agent(&flags[pass - 1]);
+    const int stamp = stamp_base + pass + 1;                              // "queued for pass + 1"
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int e = blockIdx.x * 4 + wave; e < nwl; e += gridDim.x * 4) {
-        const int key = wl[1 + e];
+        const int key = load_agent(&src[e]);
         const int mb = key / g.tiles, tile = key - mb * g.tiles;       // mb = m * nb + b
         const int b = mb % g.nb;
         const int ty_ = tile / g.tw, tx_ = tile - ty_ * g.tw;
         const int w = desc[b].w, h = desc[b].h;
         const int x0 = tx_ * CT_W, y0 = ty_ * CT_H;
         const size_t tbase = (size_t)mb * g.tiles;
-        if (pass > 0) {
-            // A tile left its last visit at its local fixed point: it has to be looked at again only if its APRON changed, i.e. if
-            // in the previous pass a neighbour promoted pixels on the border that faces this tile -- the bottom row of the tile
-            // above, the right column of the tile to the left, the bottom-right pixel (bottom row AND right column) of the tile
-            // above left ...  chg[tile] = (pass + 1) << 4 | borders changed (1 top row, 2 bottom row, 4 left column, 8 right column).
-            // Lane k looks at neighbour k (its own entry, k = 4, never asks for a visit).
-            bool hit = false;
-            if (lane < 9 && lane != 4) {
-                const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
-                const int ddx = lane % 3 - 1, ddy = lane / 3 - 1;
-                const int tx = tx_ + ddx, ty = ty_ + ddy;
-                const int need = (ddy < 0 ? 2 : (ddy > 0 ? 1 : 0)) | (ddx < 0 ? 8 : (ddx > 0 ? 4 : 0));
-                if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty) {
-                    const int v = chg_prev[tbase + ty * g.tw + tx];
-                    hit = (v >> 4) == pass && (v & need) == need;
-                }
-            }
-            if (__ballot(hit) == 0ull) continue;
-        }
         uint8_t* mp = maps + (size_t)mb * g.slot;
         const int y = y0 - 1 + lane;
         const bool row_in = lane < CT_H + 2 && y >= 0 && y < h;
@@ -261,17 +246,29 @@ __device__ __forceinline__ void hysteresis_pass(const ImgDesc* __restrict__ desc
                 }
             }
         }
-        if (lane == 0) { flags[pass] = 1; chg[tbase + tile] = ((pass + 1) << 4) | borders; }
+        // lane k queues neighbour k (k = 4 is the tile itself) if the borders that face it changed: 1 top row, 2 bottom row, 4 left
+        // column, 8 right column
+        if (lane < 9 && lane != 4 && borders != 0) {
+            const int ntx = (w + CT_W - 1) / CT_W, nty = (h + CT_H - 1) / CT_H;
+            const int ddx = lane % 3 - 1, ddy = lane / 3 - 1;
+            const int tx = tx_ + ddx, ty = ty_ + ddy;
+            const int need = (ddy > 0 ? 2 : (ddy < 0 ? 1 : 0)) | (ddx > 0 ? 8 : (ddx < 0 ? 4 : 0));
+            if (tx >= 0 && tx < ntx && ty >= 0 && ty < nty && (borders & need) == need) {
+                const int nkey = (int)tbase + ty * g.tw + tx;
+                if (atomicMax(&marks[nkey], stamp) < stamp) dst[atomicAdd(&flags[pass], 1)] = nkey;
+            }
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
                                                     uint8_t* __restrict__ edges, int* __restrict__ flags, int pass,
-                                                    const int* __restrict__ wl, int* __restrict__ chg, size_t chg_half)
+                                                    const int* __restrict__ wl, int* __restrict__ queues, size_t queue_half,
+                                                    int* __restrict__ marks, int stamp_base)
 {
     static_assert(CT_W == 64 && CT_H + 2 <= 64, "one 64-bit mask per row, one lane per row incl. the apron");
     if (pass > 0 && flags[pass - 1] == 0) return;
-    hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg, chg_half);
+    hysteresis_pass(desc, g, maps, edges, flags, pass, wl, queues, queue_half, marks, stamp_base);
 }
 
 // The tail of a phase: ONE launch behind the `first_pass` plain launches (a number the host adapts to what the previous calls
@@ -282,7 +279,8 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
 // once: a phase costs first_pass + 1 launches instead of a fixed budget of six.
 __global__ __launch_bounds__(256) void k_hysteresis_tail(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ maps,
                                                          uint8_t* __restrict__ edges, int* __restrict__ flags, int first_pass, int max_pass,
-                                                         const int* __restrict__ wl, int* __restrict__ chg, size_t chg_half,
+                                                         const int* __restrict__ wl, int* __restrict__ queues, size_t queue_half,
+                                                         int* __restrict__ marks, int stamp_base,
                                                          int* __restrict__ counter, int* __restrict__ info)
 {
     __shared__ int s_ok;
@@ -291,7 +289,7 @@ __global__ __launch_bounds__(256) void k_hysteresis_tail(const ImgDesc* __restri
     bool ok = true;
     for (; pass < max_pass; pass++) {
         if (load_agent(&flags[pass - 1]) == 0) break;                    // the previous pass changed nothing: fixed point
-        hysteresis_pass(desc, g, maps, edges, flags, pass, wl, chg, chg_half);
+        hysteresis_pass(desc, g, maps, edges, flags, pass, wl, queues, queue_half, marks, stamp_base);
         ok = grid_barrier(counter, target, &s_ok);
         if (!ok) break;
     }
