@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_hysteresis(const ImgDesc* __restrict__ 
 
 // The tail of a phase: ONE launch behind the `first_pass` plain launches (a number the host adapts to what the previous calls
 // needed), which runs whatever passes are still necessary inside the kernel -- a grid of HY_TAIL_BLOCKS workgroups with a grid-wide
-// barrier between passes -- and reports how many passes the phase took: info[0] = passes that ran until one changed nothing
+// barrier between passes -- and reports how many passes the phase took: info[0] = passes that ran until one queued nothing for the next
 // (first_pass if the plain launches had already converged), or -1 when the budget `max_pass` or a barrier timeout was hit (the
 // host then redoes the device pass with plain launches).  On diagrams the tail finds flags[first_pass - 1] == 0 and returns at
 // once: a phase costs first_pass + 1 launches instead of a fixed budget of six.
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_hysteresis_tail(const ImgDesc* __restri
     int pass = first_pass;
     bool ok = true;
     for (; pass < max_pass; pass++) {
-        if (load_agent(&flags[pass - 1]) == 0) break;                    // the previous pass changed nothing: fixed point
+        if (load_agent(&flags[pass - 1]) == 0) break;                    // the previous pass queued no tile: fixed point
         hysteresis_pass(desc, g, maps, edges, flags, pass, wl, queues, queue_half, marks, stamp_base);
         ok = grid_barrier(counter, target, &s_ok);
         if (!ok) break;
