@@ -113,7 +113,7 @@ struct i2s_ctx {
 
 // segments of i2s_last_kernel_timing, in launch order
 static const char* const kSegName[I2S_NSEG] = {
-    "k_grey", "k_blur", "k_median57_bin", "k_median57", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
+    "k_grey", "k_median57_bin", "k_blur", "k_median57", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
     "k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
     "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
 #define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
@@ -469,21 +469,23 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_SEG(0);
         if (need_grey) hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
         I2S_SEG(1);
+        {
+            // two-valued bands first (majority votes); the bit-serial kernel then redoes the tiles of bands that are not, and k_blur
+            // takes the 3x3 median of the bands that are as a majority vote too
+            const int mbx = cdiv(wmax, 1024), mby = cdiv(hmax, MB_R);    // 4 wavefronts x 256 pixels, MB_R rows
+            hipLaunchKernelGGL(k_median57_bin, dim3((unsigned)mbx * mby * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+                               plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mbx, mby);
+        }
+        I2S_SEG(2);
         if (float_blur) {
             const int bgx = cdiv(wmax, 1024), bgy = cdiv(hmax, BL_R);      // 4 wavefronts x 256 pixels, BL_R rows
             hipLaunchKernelGGL(k_blur, dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
-                               plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), bt, bgx, bgy);
+                               plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), bt,
+                               ctx->d_mflags, bgx, bgy);
         } else {
             hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
             hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GAUSS3),
                                plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
-        }
-        I2S_SEG(2);
-        {
-            // two-valued bands first (majority votes); the bit-serial kernel then redoes the tiles of bands that are not
-            const int mbx = cdiv(wmax, 1024), mby = cdiv(hmax, MB_R);    // 4 wavefronts x 256 pixels, MB_R rows
-            hipLaunchKernelGGL(k_median57_bin, dim3((unsigned)mbx * mby * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
-                               plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mbx, mby);
         }
         I2S_SEG(3);
         hipLaunchKernelGGL(k_median57, dim3((unsigned)cdiv(mx * my * nb, M_TPB)), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),

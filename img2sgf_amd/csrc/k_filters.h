@@ -147,6 +147,10 @@ __global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ de
 // Host side: used when every tap set sums to 256 (always for OpenCV's bit-exact kernels; the plain-rounding compatibility
 // mode can give 257, for which the integer kernels below remain).
 constexpr int BL_R = 64;          // output rows per wavefront (+6 apron rows of horizontal work)
+// k_median57_bin (below) walks the same 256 x 64 bands first and leaves a flag per band: 0 = every pixel the band reads is 0 or 255
+constexpr int MB_R = BL_R;        // output rows per wavefront (+6 apron rows); a band = 256 x MB_R pixels
+__device__ __host__ inline int mb_bands_x(int wmax) { return (wmax + 255) / 256; }
+__device__ __host__ inline int mb_bands_y(int hmax) { return (hmax + MB_R - 1) / MB_R; }
 struct BlurTaps { float c3, a3, c5, a5, b5, c7, a7, b7, d7; };   // centre, +-1, +-2, +-3 of the 3 / 5 / 7-tap kernels
 #define bl_f(v, byte) bl_fb<byte>(v)
 // Machine-level pieces (isa/gfx950_ops.h): imin3 / imed3 / imax3, bl_vgpr + bl_fb (taps in vector registers, bytes converted
@@ -198,12 +202,12 @@ __device__ __forceinline__ void bl_median_pixels(unsigned L, unsigned M, unsigne
 #ifndef BL_WAVES
 #define BL_WAVES 3
 #endif
-#ifndef BL_PREFETCH2
-#define BL_PREFETCH2 1
+#ifndef BL_DEPTH
+#define BL_DEPTH 4
 #endif
 __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
                                                  uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
-                                                 BlurTaps tps, int gx, int gy)
+                                                 BlurTaps tps, const int* __restrict__ band_flags, int gx, int gy)
 {
     // taps scaled by 2^-8 (exact), used in both passes: the vertical sums then are acc * 2^-16 without a final multiply
     BlurTaps tp;
@@ -221,6 +225,12 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
     const int y0 = tl.ty * BL_R;
     if (((tl.tx * 4 + wave) * 256) >= w || y0 >= h) return;          // whole wavefront outside the image
     const bool active = x0 < w;
+    // A band that k_median57_bin found to hold nothing but 0 and 255 (its test covers three rows and a dword more on every side
+    // than the 3x3 median reaches) takes its 3x3 median as a majority vote as well: the 0 / 1 bytes of the (left, mid, right)
+    // triple, a 3-sum along the row by byte shifts, the sum of three rows, and "at least 5 of 9" read off the top bit of
+    // sum + (128 - 5) -- 11 instructions per row instead of the 48 of the sorting network below.  Wave-uniform (a scalar branch).
+    const bool bin = band_flags != nullptr &&
+                     __builtin_amdgcn_readfirstlane(band_flags[((size_t)b * mb_bands_y(g.hmax) + tl.ty) * mb_bands_x(g.wmax) + tl.tx * 4 + wave]) == 0;
     const uint8_t* src = im.grey;
     const int sp = im.gpitch;
     const size_t obase = (size_t)b * g.slot;
@@ -261,6 +271,13 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
 
     float H3[7][4], H5[7][4], H7[7][4];        // horizontal results of the last 7 input rows, slot = row index mod 7
     int F1[6], F2[6];                           // median ring: pixels x0-1 .. x0+4 of the two previous rows
+    unsigned HB1 = 0, HB2 = 0;                  // two-valued bands: the row 3-sums (one byte per pixel) of the two previous rows
+    auto bin_row3 = [&](unsigned L, unsigned M, unsigned R) -> unsigned {
+        unsigned ml = L, mm = M, mr = R;
+        if (fix) { ml = __builtin_amdgcn_perm(M, L, mS[0]); mm = __builtin_amdgcn_perm(M, L, mS[1]); mr = __builtin_amdgcn_perm(R, M, mS[2]); }
+        const unsigned fl = ml & 0x01010101u, fm = mm & 0x01010101u, fr = mr & 0x01010101u;
+        return alignbyte(fm, fl, 3) + fm + alignbyte(fr, fm, 1);      // byte q: pixels x0 + q - 1 .. x0 + q + 1
+    };
 #pragma unroll
     for (int i = 0; i < 7; i++)
 #pragma unroll
@@ -271,7 +288,8 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
     if (y0 == 0) {
         // BORDER_REPLICATE above the image: the ring starts out holding row 0 as "row -1"
         const unsigned M = bl_bload(sbuf, 0, xm), E = bl_bload(sbuf, 0, xe);
-        bl_median_pixels(bl_from_prev_lane(M, E), M, bl_from_next_lane(M, E), fix, mS, F1);
+        if (bin) HB1 = bin_row3(bl_from_prev_lane(M, E), M, bl_from_next_lane(M, E));
+        else bl_median_pixels(bl_from_prev_lane(M, E), M, bl_from_next_lane(M, E), fix, mS, F1);
     }
 
     // the loads of row t + 1 are in flight while row t is computed
@@ -283,15 +301,16 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
         nM = bl_bload(sbuf, ro, xm);
         nE = bl_bload(sbuf, ro, xe);
     }
-#if BL_PREFETCH2
-    unsigned n2M, n2E;                       // a second row in flight
-    {
+    // BL_DEPTH rows in flight in all: vmcnt counts loads and stores together and in order, so the wait for a row's pixels is also a
+    // wait for every store issued before that load -- the deeper the queue, the more rows of stores may still be on their way
+    unsigned qM[BL_DEPTH - 1], qE[BL_DEPTH - 1];
+#pragma unroll
+    for (int d = 0; d < BL_DEPTH - 1; d++) {
         ry.step();
         const int ro = rowoff(ry.y, sp);
-        n2M = bl_bload(sbuf, ro, xm);
-        n2E = bl_bload(sbuf, ro, xe);
+        qM[d] = bl_bload(sbuf, ro, xm);
+        qE[d] = bl_bload(sbuf, ro, xe);
     }
-#endif
     static_assert((BL_R + 6) % 7 == 0, "the row loop is unrolled by the ring depth");
     const int t_end = imin(BL_R + 6, h + 3 - (y0 - 3));               // input rows beyond h + 2 feed no output of this band
     const BlBuf o_m = bl_buf(med3 + obase), o_3 = bl_buf(out3 + obase), o_5 = bl_buf(out5 + obase), o_7 = bl_buf(out7 + obase);
@@ -301,22 +320,15 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
             const int t = t0 + u;
             const int yi = y0 - 3 + t;
             const unsigned M = nM, E = nE;
-#if BL_PREFETCH2
-            nM = n2M; nE = n2E;
+            nM = qM[0]; nE = qE[0];
+#pragma unroll
+            for (int d = 0; d + 1 < BL_DEPTH - 1; d++) { qM[d] = qM[d + 1]; qE[d] = qE[d + 1]; }
             {
                 ry.step();
                 const int ro = rowoff(ry.y, sp);
-                n2M = bl_bload(sbuf, ro, xm);
-                n2E = bl_bload(sbuf, ro, xe);
+                qM[BL_DEPTH - 2] = bl_bload(sbuf, ro, xm);
+                qE[BL_DEPTH - 2] = bl_bload(sbuf, ro, xe);
             }
-#else
-            {
-                ry.step();
-                const int ro = rowoff(ry.y, sp);
-                nM = bl_bload(sbuf, ro, xm);
-                nE = bl_bload(sbuf, ro, xe);
-            }
-#endif
             const unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E);
             unsigned gl = L, gm = M, gr = R;
             if (fix) {
@@ -342,13 +354,20 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
             // 3x3 median: image row yi completes output row yi - 1 (rows yi - 2, yi - 1, yi = F2, F1, F0); the last image
             // row also completes itself (BORDER_REPLICATE below the image: rows h - 2, h - 1, h - 1)
             if (yi >= 0 && yi < h) {
-                int F0[6];
-                bl_median_pixels(L, M, R, fix, mS, F0);
                 const int ym = yi - 1;
-                if (ym >= y0 && ym < y0 + BL_R) { om = bl_median_row(F2, F1, F0); st_m = true; }
-                if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) { om2 = bl_median_row(F1, F0, F0); st_m2 = true; }
+                if (bin) {
+                    const unsigned hb0 = bin_row3(L, M, R);
+                    if (ym >= y0 && ym < y0 + BL_R) { om = bytes_from_sign(HB2 + HB1 + hb0 + 0x7b7b7b7bu); st_m = true; }
+                    if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) { om2 = bytes_from_sign(HB1 + hb0 + hb0 + 0x7b7b7b7bu); st_m2 = true; }
+                    HB2 = HB1; HB1 = hb0;
+                } else {
+                    int F0[6];
+                    bl_median_pixels(L, M, R, fix, mS, F0);
+                    if (ym >= y0 && ym < y0 + BL_R) { om = bl_median_row(F2, F1, F0); st_m = true; }
+                    if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) { om2 = bl_median_row(F1, F0, F0); st_m2 = true; }
 #pragma unroll
-                for (int i = 0; i < 6; i++) { F2[i] = F1[i]; F1[i] = F0[i]; }
+                    for (int i = 0; i < 6; i++) { F2[i] = F1[i]; F1[i] = F0[i]; }
+                }
             }
             // vertical pass: output row yo = yi - 3 from ring slots t-6 .. t (centre t-3)
             const int yo = yi - 3;
@@ -451,9 +470,6 @@ __global__ __launch_bounds__(256) void k_median3(const ImgDesc* __restrict__ des
 // byte that is neither 0 nor 255; at the first such byte the wavefront raises its band's flag and leaves.  k_median57 (the
 // general bit-serial kernel, below) then runs on every tile that touches a flagged band and overwrites whatever the band
 // wrote; tiles whose bands all stayed silent return at once.  Either way every output pixel is an exact median.
-constexpr int MB_R = 64;          // output rows per wavefront (+6 apron rows); a band = 256 x MB_R pixels
-__device__ __host__ inline int mb_bands_x(int wmax) { return (wmax + 255) / 256; }
-__device__ __host__ inline int mb_bands_y(int hmax) { return (hmax + MB_R - 1) / MB_R; }
 
 // flags[(b * bands_y + band row) * bands_x + column group] != 0: the band holds a pixel other than 0 / 255 (zeroed by the host)
 __global__ __launch_bounds__(256) void k_median57_bin(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ out5,
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(256) void k_median57_bin(const ImgDesc* __restrict_
     unsigned S5 = 0, S7 = 0;                    // vertical running sums
     const BlBuf sbuf = bl_buf(im.grey);
     const int sp = im.gpitch;
-    // two rows in flight (the kernel is bound by memory latency, not by its dozen instructions per pixel)
+    // two rows in flight (the kernel is bound by memory latency, not by its dozen instructions per pixel; 4, 6, 8 rows: no faster)
     unsigned nM, nE, n2M, n2E;
     {
         const int ro = rowoff(iclamp(y0 - 3, 0, h - 1), sp), ro2 = rowoff(iclamp(y0 - 2, 0, h - 1), sp);
