@@ -5,7 +5,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libi2s_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+# -fno-slp-vectorize: left alone the compiler pairs adjacent scalar f32 operations into v_pk_add / v_pk_fma_f32, which on gfx950 take
+# 4.7 cycles against 2 x 2.9 and need their operands moved into aligned register pairs first (k_blur: 628 packed operations and 200
+# more v_mov, 17 more VGPRs; 2.13 -> 2.07 us per diagram without them -- MI355X_MICROARCH.md calls the packing an anti-lever)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(CSRC, "isa")]
 
 

@@ -469,20 +469,20 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_SEG(0);
         if (need_grey) hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
         I2S_SEG(1);
-        {
-            // two-valued bands first (majority votes); the bit-serial kernel then redoes the tiles of bands that are not, and k_blur
-            // takes the 3x3 median of the bands that are as a majority vote too
+        if (float_blur) {
+            // the three Gaussians and the 3x3 median; bands of pure 0 / 255 pixels get their 5x5 / 7x7 medians here as well (majority
+            // votes), the others are flagged for the bit-serial kernel
+            const int bgx = cdiv(wmax, 1024), bgy = cdiv(hmax, BL_R);      // 4 wavefronts x 256 pixels, BL_R rows
+            I2S_SEG(2);                                                    // (the k_median57_bin segment stays empty on this path)
+            hipLaunchKernelGGL(k_blur, dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
+                               plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7),
+                               plane_ptr(ctx, I2S_PLANE_MEDIAN5), plane_ptr(ctx, I2S_PLANE_MEDIAN7), bt, ctx->d_mflags, bgx, bgy);
+        } else {
+            // integer kernels (tap sets that do not sum to 256): the two-valued bands' 5x5 / 7x7 majority votes have a kernel of their own
             const int mbx = cdiv(wmax, 1024), mby = cdiv(hmax, MB_R);    // 4 wavefronts x 256 pixels, MB_R rows
             hipLaunchKernelGGL(k_median57_bin, dim3((unsigned)mbx * mby * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                                plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mbx, mby);
-        }
-        I2S_SEG(2);
-        if (float_blur) {
-            const int bgx = cdiv(wmax, 1024), bgy = cdiv(hmax, BL_R);      // 4 wavefronts x 256 pixels, BL_R rows
-            hipLaunchKernelGGL(k_blur, dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
-                               plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), bt,
-                               ctx->d_mflags, bgx, bgy);
-        } else {
+            I2S_SEG(2);
             hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
             hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GAUSS3),
                                plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);

@@ -4,6 +4,7 @@
 //   GaussianBlur 8U     (smooth.dispatch.cpp / smooth.simd.hpp fixed-point 8.8 taps, REFLECT_101)
 //   medianBlur 8U       (median_blur.simd.hpp, exact median, REPLICATE)
 #pragma once
+#include <type_traits>
 #include "i2s_types.h"
 #include "tile_io.h"
 #include <gfx950_ops.h>
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ de
 // Host side: used when every tap set sums to 256 (always for OpenCV's bit-exact kernels; the plain-rounding compatibility
 // mode can give 257, for which the integer kernels below remain).
 constexpr int BL_R = 64;          // output rows per wavefront (+6 apron rows of horizontal work)
-// k_median57_bin (below) walks the same 256 x 64 bands first and leaves a flag per band: 0 = every pixel the band reads is 0 or 255
+// bands of the two-valued speculation (k_blur; k_median57_bin for the integer-kernel path): a flag per 256 x 64 band
 constexpr int MB_R = BL_R;        // output rows per wavefront (+6 apron rows); a band = 256 x MB_R pixels
 __device__ __host__ inline int mb_bands_x(int wmax) { return (wmax + 255) / 256; }
 __device__ __host__ inline int mb_bands_y(int hmax) { return (hmax + MB_R - 1) / MB_R; }
@@ -203,11 +204,24 @@ __device__ __forceinline__ void bl_median_pixels(unsigned L, unsigned M, unsigne
 #define BL_WAVES 3
 #endif
 #ifndef BL_DEPTH
-#define BL_DEPTH 4
+#define BL_DEPTH 6        // rows of loads in flight (3: 2.18, 4: 2.04, 5 / 6: 1.93, 8: 1.91 us per diagram)
 #endif
+// Two-valued bands.  A diagram of pure black and white (the benchmark's; a scan after the reference's contrast step mostly) needs no
+// median machinery: with every pixel of the window 0 or 255 the 3x3 / 5x5 / 7x7 median is 255 iff at least 5 of 9 / 13 of 25 / 25
+// of 49 are -- box sums and a compare, separable.  k_blur SPECULATES that its band (256 x BL_R pixels plus three rows and a dword on
+// every side: everything the 7x7 window reaches) is such a band and then writes all six planes of the blur bank itself: per row the
+// pixels become 0 / 1 bytes, the horizontal 3-, 5- and 7-sums are byte-shifted adds of the (left, mid, right) dword triple (no
+// carries: a byte never exceeds 49), packed 2 + 3 + 3 bits per byte into ONE ring register per row; three running sums follow the
+// rows, and sum + (128 - need) has its top bit set exactly when the majority is 255 (v_perm's sign selectors turn it into the byte).
+// Every dword the band reads is tested for a byte that is neither 0 nor 255 (a byte is one of the two iff each bit equals the
+// next higher one); at the first such byte the wavefront raises the band's flag and starts over in the general mode: Gaussians + the
+// 3x3 sorting network, and k_median57 (the bit-serial kernel, below) then computes the 5x5 / 7x7 medians of every tile that touches a
+// flagged band, overwriting whatever the speculation had written.  Either way every output pixel is exact.
+// flags[(b * bands_y + band row) * bands_x + column group] != 0: the band holds a pixel other than 0 / 255 (zeroed by the host)
 __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
                                                  uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
-                                                 BlurTaps tps, const int* __restrict__ band_flags, int gx, int gy)
+                                                 uint8_t* __restrict__ med5, uint8_t* __restrict__ med7,
+                                                 BlurTaps tps, int* __restrict__ band_flags, int gx, int gy)
 {
     // taps scaled by 2^-8 (exact), used in both passes: the vertical sums then are acc * 2^-16 without a final multiply
     BlurTaps tp;
@@ -221,16 +235,11 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
     const ImgDesc im = desc[b];
     const int w = im.w, h = im.h;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x0 = ((tl.tx * 4 + wave) * 64 + lane) * 4;
+    const int cgp = tl.tx * 4 + wave;                                // 256-pixel column group
+    const int x0 = (cgp * 64 + lane) * 4;
     const int y0 = tl.ty * BL_R;
-    if (((tl.tx * 4 + wave) * 256) >= w || y0 >= h) return;          // whole wavefront outside the image
+    if (cgp * 256 >= w || y0 >= h) return;                            // whole wavefront outside the image
     const bool active = x0 < w;
-    // A band that k_median57_bin found to hold nothing but 0 and 255 (its test covers three rows and a dword more on every side
-    // than the 3x3 median reaches) takes its 3x3 median as a majority vote as well: the 0 / 1 bytes of the (left, mid, right)
-    // triple, a 3-sum along the row by byte shifts, the sum of three rows, and "at least 5 of 9" read off the top bit of
-    // sum + (128 - 5) -- 11 instructions per row instead of the 48 of the sorting network below.  Wave-uniform (a scalar branch).
-    const bool bin = band_flags != nullptr &&
-                     __builtin_amdgcn_readfirstlane(band_flags[((size_t)b * mb_bands_y(g.hmax) + tl.ty) * mb_bands_x(g.wmax) + tl.tx * 4 + wave]) == 0;
     const uint8_t* src = im.grey;
     const int sp = im.gpitch;
     const size_t obase = (size_t)b * g.slot;
@@ -268,144 +277,199 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
     // for the other lanes, which makes the compiler wait for the previous load before it issues the next one.
     const bool has_e = (lane == 0 && x0 >= 4) || (lane == 63 && x0 + 4 < w);
     const unsigned xm = active ? (unsigned)x0 : 0u, xe = has_e ? (unsigned)(lane == 0 ? x0 - 4 : x0 + 4) : 0u;
-
-    float H3[7][4], H5[7][4], H7[7][4];        // horizontal results of the last 7 input rows, slot = row index mod 7
-    int F1[6], F2[6];                           // median ring: pixels x0-1 .. x0+4 of the two previous rows
-    unsigned HB1 = 0, HB2 = 0;                  // two-valued bands: the row 3-sums (one byte per pixel) of the two previous rows
-    auto bin_row3 = [&](unsigned L, unsigned M, unsigned R) -> unsigned {
-        unsigned ml = L, mm = M, mr = R;
-        if (fix) { ml = __builtin_amdgcn_perm(M, L, mS[0]); mm = __builtin_amdgcn_perm(M, L, mS[1]); mr = __builtin_amdgcn_perm(R, M, mS[2]); }
-        const unsigned fl = ml & 0x01010101u, fm = mm & 0x01010101u, fr = mr & 0x01010101u;
-        return alignbyte(fm, fl, 3) + fm + alignbyte(fr, fm, 1);      // byte q: pixels x0 + q - 1 .. x0 + q + 1
-    };
+    // bits 0 .. 6 of the bytes of the lane's dwords that are pixels of the image (only those are tested for "neither 0 nor 255")
+    unsigned vm = 0, ve = 0;
 #pragma unroll
-    for (int i = 0; i < 7; i++)
+    for (int q = 0; q < 4; q++) if (active && x0 + q < w) vm |= 0x7fu << (8 * q);
+    if (has_e) {
+        const int xe0 = lane == 0 ? x0 - 4 : x0 + 4;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { H3[i][q] = 0.f; H5[i][q] = 0.f; H7[i][q] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 6; i++) { F1[i] = 0; F2[i] = 0; }
+        for (int q = 0; q < 4; q++) if (xe0 + q < w) ve |= 0x7fu << (8 * q);
+    }
     const BlBuf sbuf = bl_buf(src);
-    if (y0 == 0) {
-        // BORDER_REPLICATE above the image: the ring starts out holding row 0 as "row -1"
-        const unsigned M = bl_bload(sbuf, 0, xm), E = bl_bload(sbuf, 0, xe);
-        if (bin) HB1 = bin_row3(bl_from_prev_lane(M, E), M, bl_from_next_lane(M, E));
-        else bl_median_pixels(bl_from_prev_lane(M, E), M, bl_from_next_lane(M, E), fix, mS, F1);
-    }
-
-    // the loads of row t + 1 are in flight while row t is computed
-    BlReflect ry;
-    ry.init(y0 - 3, h);
-    unsigned nM, nE;
-    {
-        const int ro = rowoff(ry.y, sp);
-        nM = bl_bload(sbuf, ro, xm);
-        nE = bl_bload(sbuf, ro, xe);
-    }
-    // BL_DEPTH rows in flight in all: vmcnt counts loads and stores together and in order, so the wait for a row's pixels is also a
-    // wait for every store issued before that load -- the deeper the queue, the more rows of stores may still be on their way
-    unsigned qM[BL_DEPTH - 1], qE[BL_DEPTH - 1];
-#pragma unroll
-    for (int d = 0; d < BL_DEPTH - 1; d++) {
-        ry.step();
-        const int ro = rowoff(ry.y, sp);
-        qM[d] = bl_bload(sbuf, ro, xm);
-        qE[d] = bl_bload(sbuf, ro, xe);
-    }
+    const BlBuf o_m = bl_buf(med3 + obase), o_3 = bl_buf(out3 + obase), o_5 = bl_buf(out5 + obase), o_7 = bl_buf(out7 + obase);
+    const BlBuf o_m5 = bl_buf(med5 + obase), o_m7 = bl_buf(med7 + obase);
     static_assert((BL_R + 6) % 7 == 0, "the row loop is unrolled by the ring depth");
     const int t_end = imin(BL_R + 6, h + 3 - (y0 - 3));               // input rows beyond h + 2 feed no output of this band
-    const BlBuf o_m = bl_buf(med3 + obase), o_3 = bl_buf(out3 + obase), o_5 = bl_buf(out5 + obase), o_7 = bl_buf(out7 + obase);
-    for (int t0 = 0; t0 < t_end; t0 += 7) {
+
+    // the median's (left, mid, right) triple of a row: BORDER_REPLICATE along x
+    auto med_triple = [&](unsigned L, unsigned M, unsigned R, unsigned& ml, unsigned& mm, unsigned& mr) {
+        ml = L; mm = M; mr = R;
+        if (fix) { ml = __builtin_amdgcn_perm(M, L, mS[0]); mm = __builtin_amdgcn_perm(M, L, mS[1]); mr = __builtin_amdgcn_perm(R, M, mS[2]); }
+    };
+    // two-valued rows: the horizontal 3- / 5- / 7-sums of the 0 / 1 bytes, packed h3 | h5 << 2 | h7 << 5 per pixel byte
+    auto bin_row = [&](unsigned L, unsigned M, unsigned R) -> unsigned {
+        unsigned ml, mm, mr;
+        med_triple(L, M, R, ml, mm, mr);
+        const unsigned fl = ml & 0x01010101u, fm = mm & 0x01010101u, fr = mr & 0x01010101u;
+        // byte q of the sums = pixel x0 + q: pixels x0 + q - 3 .. x0 + q + 3 are bytes q + 1 .. q + 7 of the triple
+        const unsigned h3 = alignbyte(fm, fl, 3) + fm + alignbyte(fr, fm, 1);
+        const unsigned h5 = h3 + alignbyte(fm, fl, 2) + alignbyte(fr, fm, 2);
+        const unsigned h7 = h5 + alignbyte(fm, fl, 1) + alignbyte(fr, fm, 3);
+        return h3 | (h5 << 2) | (h7 << 5);
+    };
+
+    // One walk down the band.  BIN: the speculative mode (returns false at the first byte that is neither 0 nor 255).
+    auto walk = [&](auto bin_tag) -> bool {
+        constexpr bool BIN = decltype(bin_tag)::value;
+        float H3[7][4], H5[7][4], H7[7][4];        // horizontal results of the last 7 input rows, slot = row index mod 7
+        int F1[6], F2[6];                           // general mode, 3x3 median ring: pixels x0-1 .. x0+4 of the two previous rows
+        unsigned RB[7];                             // BIN: packed row sums of the last 7 rows (BORDER_REPLICATE rows), slot = row index mod 7
+        unsigned S3 = 0, S5 = 0, S7 = 0;            // BIN: vertical running sums (rows t-4 .. t-2, t-5 .. t-1, t-6 .. t)
+        unsigned p_first = 0, p_last = 0;           // BIN: packed sums of image row 0 (bands at the top) / of the latest image row
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int t = t0 + u;
-            const int yi = y0 - 3 + t;
-            const unsigned M = nM, E = nE;
-            nM = qM[0]; nE = qE[0];
+        for (int i = 0; i < 7; i++) {
+            RB[i] = 0;
 #pragma unroll
-            for (int d = 0; d + 1 < BL_DEPTH - 1; d++) { qM[d] = qM[d + 1]; qE[d] = qE[d + 1]; }
-            {
-                ry.step();
-                const int ro = rowoff(ry.y, sp);
-                qM[BL_DEPTH - 2] = bl_bload(sbuf, ro, xm);
-                qE[BL_DEPTH - 2] = bl_bload(sbuf, ro, xe);
-            }
+            for (int q = 0; q < 4; q++) { H3[i][q] = 0.f; H5[i][q] = 0.f; H7[i][q] = 0.f; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) { F1[i] = 0; F2[i] = 0; }
+        if (y0 == 0) {
+            // BORDER_REPLICATE above the image: rows -3 .. -1 are row 0
+            const unsigned M = bl_bload(sbuf, 0, xm), E = bl_bload(sbuf, 0, xe);
             const unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E);
-            unsigned gl = L, gm = M, gr = R;
-            if (fix) {
-                gl = __builtin_amdgcn_perm(M, L, gA[0]);
-                gm = __builtin_amdgcn_perm(M, L, gA[1]);
-                gr = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[2]), gB2);
-            }
-            float f[10];                                              // pixels x0 - 3 .. x0 + 6
-            f[0] = bl_f(gl, 1); f[1] = bl_f(gl, 2); f[2] = bl_f(gl, 3);
-            f[3] = bl_f(gm, 0); f[4] = bl_f(gm, 1); f[5] = bl_f(gm, 2); f[6] = bl_f(gm, 3);
-            f[7] = bl_f(gr, 0); f[8] = bl_f(gr, 1); f[9] = bl_f(gr, 2);
-            // horizontal pass of the three Gaussians into ring slot u
+            if (BIN) {
+                if (__any(((((M >> 1) ^ M) & vm) | (((E >> 1) ^ E) & ve)) != 0u)) return false;
+                p_first = bin_row(L, M, R);
+            } else bl_median_pixels(L, M, R, fix, mS, F1);
+        }
+        // BL_DEPTH rows in flight: vmcnt counts loads and stores together and in order, so the wait for a row's pixels is also a
+        // wait for every store issued before that load -- the deeper the queue, the more rows of stores may still be on their way
+        BlReflect ry;
+        ry.init(y0 - 3, h);
+        unsigned nM, nE;
+        {
+            const int ro = rowoff(ry.y, sp);
+            nM = bl_bload(sbuf, ro, xm);
+            nE = bl_bload(sbuf, ro, xe);
+        }
+        unsigned qM[BL_DEPTH - 1], qE[BL_DEPTH - 1];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float c = f[q + 3];
-                const float s1 = f[q + 2] + f[q + 4], s2 = f[q + 1] + f[q + 5], s3 = f[q] + f[q + 6];
-                H3[u][q] = __builtin_fmaf(tp.a3, s1, tp.c3 * c);
-                H5[u][q] = __builtin_fmaf(tp.b5, s2, __builtin_fmaf(tp.a5, s1, tp.c5 * c));
-                H7[u][q] = __builtin_fmaf(tp.d7, s3, __builtin_fmaf(tp.b7, s2, __builtin_fmaf(tp.a7, s1, tp.c7 * c)));
-            }
-            unsigned om = 0, om2 = 0;
-            bool st_m = false, st_m2 = false;
-            // 3x3 median: image row yi completes output row yi - 1 (rows yi - 2, yi - 1, yi = F2, F1, F0); the last image
-            // row also completes itself (BORDER_REPLICATE below the image: rows h - 2, h - 1, h - 1)
-            if (yi >= 0 && yi < h) {
-                const int ym = yi - 1;
-                if (bin) {
-                    const unsigned hb0 = bin_row3(L, M, R);
-                    if (ym >= y0 && ym < y0 + BL_R) { om = bytes_from_sign(HB2 + HB1 + hb0 + 0x7b7b7b7bu); st_m = true; }
-                    if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) { om2 = bytes_from_sign(HB1 + hb0 + hb0 + 0x7b7b7b7bu); st_m2 = true; }
-                    HB2 = HB1; HB1 = hb0;
-                } else {
+        for (int d = 0; d < BL_DEPTH - 1; d++) {
+            ry.step();
+            const int ro = rowoff(ry.y, sp);
+            qM[d] = bl_bload(sbuf, ro, xm);
+            qE[d] = bl_bload(sbuf, ro, xe);
+        }
+        for (int t0 = 0; t0 < t_end; t0 += 7) {
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const int t = t0 + u;
+                const int yi = y0 - 3 + t;
+                const unsigned M = nM, E = nE;
+                nM = qM[0]; nE = qE[0];
+#pragma unroll
+                for (int d = 0; d + 1 < BL_DEPTH - 1; d++) { qM[d] = qM[d + 1]; qE[d] = qE[d + 1]; }
+                {
+                    ry.step();
+                    const int ro = rowoff(ry.y, sp);
+                    qM[BL_DEPTH - 2] = bl_bload(sbuf, ro, xm);
+                    qE[BL_DEPTH - 2] = bl_bload(sbuf, ro, xe);
+                }
+                if (BIN) {
+                    const unsigned odd = (((M >> 1) ^ M) & vm) | (((E >> 1) ^ E) & ve);
+                    if (__any(odd != 0u)) return false;
+                }
+                const unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E);
+                unsigned gl = L, gm = M, gr = R;
+                if (fix) {
+                    gl = __builtin_amdgcn_perm(M, L, gA[0]);
+                    gm = __builtin_amdgcn_perm(M, L, gA[1]);
+                    gr = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[2]), gB2);
+                }
+                float f[10];                                              // pixels x0 - 3 .. x0 + 6
+                f[0] = bl_f(gl, 1); f[1] = bl_f(gl, 2); f[2] = bl_f(gl, 3);
+                f[3] = bl_f(gm, 0); f[4] = bl_f(gm, 1); f[5] = bl_f(gm, 2); f[6] = bl_f(gm, 3);
+                f[7] = bl_f(gr, 0); f[8] = bl_f(gr, 1); f[9] = bl_f(gr, 2);
+                // horizontal pass of the three Gaussians into ring slot u
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float c = f[q + 3];
+                    const float s1 = f[q + 2] + f[q + 4], s2 = f[q + 1] + f[q + 5], s3 = f[q] + f[q + 6];
+                    H3[u][q] = __builtin_fmaf(tp.a3, s1, tp.c3 * c);
+                    H5[u][q] = __builtin_fmaf(tp.b5, s2, __builtin_fmaf(tp.a5, s1, tp.c5 * c));
+                    H7[u][q] = __builtin_fmaf(tp.d7, s3, __builtin_fmaf(tp.b7, s2, __builtin_fmaf(tp.a7, s1, tp.c7 * c)));
+                }
+                const int yo = yi - 3;
+                const bool st_g = t >= 6 && yo < h;
+                unsigned om = 0, om2 = 0, om5 = 0, om7 = 0;
+                bool st_m = false, st_m2 = false;
+                if (BIN) {
+                    // the medians' row is BORDER_REPLICATE: rows above the image are row 0, rows below it the last one (the loaded row
+                    // is the Gaussians' REFLECT_101 row there)
+                    unsigned p;
+                    if (yi < 0) p = p_first;
+                    else if (yi >= h) p = p_last;
+                    else { p = bin_row(L, M, R); p_last = p; }
+                    const unsigned old = RB[u];                               // row t - 7
+                    S7 += ((p >> 5) & 0x07070707u) - ((old >> 5) & 0x07070707u);
+                    S5 += ((RB[(u + 6) % 7] >> 2) & 0x07070707u) - ((RB[(u + 1) % 7] >> 2) & 0x07070707u);
+                    S3 += (RB[(u + 5) % 7] & 0x03030303u) - (RB[(u + 2) % 7] & 0x03030303u);
+                    RB[u] = p;
+                    om = bytes_from_sign(S3 + 0x7b7b7b7bu);                   // + (128 - 5): top bit <=> at least 5 of 9
+                    om5 = bytes_from_sign(S5 + 0x73737373u);                  // + (128 - 13)
+                    om7 = bytes_from_sign(S7 + 0x67676767u);                  // + (128 - 25)
+                } else if (yi >= 0 && yi < h) {
+                    // 3x3 median: image row yi completes output row yi - 1 (rows yi - 2, yi - 1, yi = F2, F1, F0); the last image
+                    // row also completes itself (BORDER_REPLICATE below the image: rows h - 2, h - 1, h - 1)
                     int F0[6];
                     bl_median_pixels(L, M, R, fix, mS, F0);
+                    const int ym = yi - 1;
                     if (ym >= y0 && ym < y0 + BL_R) { om = bl_median_row(F2, F1, F0); st_m = true; }
                     if (yi == h - 1 && yi >= y0 && yi < y0 + BL_R) { om2 = bl_median_row(F1, F0, F0); st_m2 = true; }
 #pragma unroll
                     for (int i = 0; i < 6; i++) { F2[i] = F1[i]; F1[i] = F0[i]; }
                 }
-            }
-            // vertical pass: output row yo = yi - 3 from ring slots t-6 .. t (centre t-3)
-            const int yo = yi - 3;
-            unsigned o3w = 0, o5w = 0, o7w = 0;
-            const bool st_g = t >= 6 && yo < h;
-            if (st_g) {
-                constexpr int NS = 7;
-                const int c = (u + 4) % NS, p1 = (u + 5) % NS, m1 = (u + 3) % NS, p2 = (u + 6) % NS, m2 = (u + 2) % NS, p3 = u, m3 = (u + 1) % NS;
-                float r3[4], r5[4], r7[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    r3[q] = bl_round16(__builtin_fmaf(tp.a3, H3[p1][q] + H3[m1][q], tp.c3 * H3[c][q]));
-                    r5[q] = bl_round16(__builtin_fmaf(tp.b5, H5[p2][q] + H5[m2][q],
-                                                      __builtin_fmaf(tp.a5, H5[p1][q] + H5[m1][q], tp.c5 * H5[c][q])));
-                    r7[q] = bl_round16(__builtin_fmaf(tp.d7, H7[p3][q] + H7[m3][q],
-                                                      __builtin_fmaf(tp.b7, H7[p2][q] + H7[m2][q],
-                                                                     __builtin_fmaf(tp.a7, H7[p1][q] + H7[m1][q], tp.c7 * H7[c][q]))));
-                }
-                o3w = bl_pack(r3[0], r3[1], r3[2], r3[3]);
-                o5w = bl_pack(r5[0], r5[1], r5[2], r5[3]);
-                o7w = bl_pack(r7[0], r7[1], r7[2], r7[3]);
-            }
-            // the stores of this row go out AFTER the wait for the next row's pixels (see BL_CONSUME)
-            BL_SCHED_FENCE();
-            BL_CONSUME(nM, nE);
-            BL_SCHED_FENCE();
-            if (active) {
-                if (st_m) bl_bstore(o_m, rowoff(yi - 1, g.pitch), xm, om);
-                if (st_m2) bl_bstore(o_m, rowoff(yi, g.pitch), xm, om2);
+                // vertical pass: output row yo = yi - 3 from ring slots t-6 .. t (centre t-3)
+                unsigned o3w = 0, o5w = 0, o7w = 0;
                 if (st_g) {
-                    const int off = rowoff(yo, g.pitch);
-                    bl_bstore(o_3, off, xm, o3w);
-                    bl_bstore(o_5, off, xm, o5w);
-                    bl_bstore(o_7, off, xm, o7w);
+                    constexpr int NS = 7;
+                    const int c = (u + 4) % NS, p1 = (u + 5) % NS, m1 = (u + 3) % NS, p2 = (u + 6) % NS, m2 = (u + 2) % NS, p3 = u, m3 = (u + 1) % NS;
+                    float r3[4], r5[4], r7[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        r3[q] = bl_round16(__builtin_fmaf(tp.a3, H3[p1][q] + H3[m1][q], tp.c3 * H3[c][q]));
+                        r5[q] = bl_round16(__builtin_fmaf(tp.b5, H5[p2][q] + H5[m2][q],
+                                                          __builtin_fmaf(tp.a5, H5[p1][q] + H5[m1][q], tp.c5 * H5[c][q])));
+                        r7[q] = bl_round16(__builtin_fmaf(tp.d7, H7[p3][q] + H7[m3][q],
+                                                          __builtin_fmaf(tp.b7, H7[p2][q] + H7[m2][q],
+                                                                         __builtin_fmaf(tp.a7, H7[p1][q] + H7[m1][q], tp.c7 * H7[c][q]))));
+                    }
+                    o3w = bl_pack(r3[0], r3[1], r3[2], r3[3]);
+                    o5w = bl_pack(r5[0], r5[1], r5[2], r5[3]);
+                    o7w = bl_pack(r7[0], r7[1], r7[2], r7[3]);
+                }
+                // the stores of this row go out AFTER the wait for the next row's pixels (see BL_CONSUME)
+                BL_SCHED_FENCE();
+                BL_CONSUME(nM, nE);
+                BL_SCHED_FENCE();
+                if (active) {
+                    if (!BIN) {
+                        if (st_m) bl_bstore(o_m, rowoff(yi - 1, g.pitch), xm, om);
+                        if (st_m2) bl_bstore(o_m, rowoff(yi, g.pitch), xm, om2);
+                    }
+                    if (st_g) {
+                        const int off = rowoff(yo, g.pitch);
+                        bl_bstore(o_3, off, xm, o3w);
+                        bl_bstore(o_5, off, xm, o5w);
+                        bl_bstore(o_7, off, xm, o7w);
+                        if (BIN) {
+                            bl_bstore(o_m, off, xm, om);
+                            bl_bstore(o_m5, off, xm, om5);
+                            bl_bstore(o_m7, off, xm, om7);
+                        }
+                    }
                 }
             }
         }
+        return true;
+    };
+    if (band_flags != nullptr) {
+        if (walk(std::true_type{})) return;
+        if (lane == 0) band_flags[((size_t)b * mb_bands_y(g.hmax) + tl.ty) * mb_bands_x(g.wmax) + cgp] = 1;
     }
+    walk(std::false_type{});
 }
 
 // ---- K4: exact medians, BORDER_REPLICATE (cv.medianBlur, img2sgf.py:174).
