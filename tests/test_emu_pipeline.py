@@ -282,6 +282,16 @@ def test_blur_bank_shapes_emulated(lib):
     im = (rng.integers(0, 256, (41, 60)) & 0xF0).astype(np.uint8)
     det.detect_batch([im], full=False)
     np.testing.assert_array_equal(det.fetch_plane(0, "median7"), cvo.median_blur(im, 7))
+    # k_blur's two-valued speculation: a 0 / 255 image stays in that mode, one stray grey pixel restarts its band in the general one
+    base = np.where(rng.integers(0, 2, (70, 260)) == 0, 0, 255).astype(np.uint8)
+    for spot in (None, (0, 0, 128), (63, 255, 254), (64, 256, 1), (66, 259, 100), (69, 3, 77)):
+        im = base.copy()
+        if spot: im[spot[0], spot[1]] = spot[2]
+        det.detect_batch([im], full=False)
+        for name, kk in (("gauss3", 3), ("gauss5", 5), ("gauss7", 7)):
+            np.testing.assert_array_equal(det.fetch_plane(0, name), cvo.gaussian_blur(im, kk, kk), err_msg="%s spot %s" % (name, spot))
+        for name, kk in (("median3", 3), ("median5", 5), ("median7", 7)):
+            np.testing.assert_array_equal(det.fetch_plane(0, name), cvo.median_blur(im, kk), err_msg="%s spot %s" % (name, spot))
     det.detect_batch([np.full((20, 40), 255, np.uint8)], Params(gauss_kernel_mode=1), full=False)     # tap sums != 256: integer kernels
     np.testing.assert_array_equal(det.fetch_plane(0, "gauss7"), cvo.gaussian_blur(np.full((20, 40), 255, np.uint8), 7, 7, 1))
     det.close()

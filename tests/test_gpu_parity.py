@@ -424,6 +424,28 @@ def test_blur_bank_shapes():
     det.close()
 
 
+def test_two_valued_band_speculation_restarts():
+    """k_blur walks a band as if it held nothing but 0 and 255 and starts over in the general mode at the first other byte:
+    0 / 255 images with ONE stray grey pixel -- deep inside a band, in its first and last rows, in the three halo rows it shares
+    with the band above / below, in the dword a wavefront borrows from its neighbour, in the last column / row of the image --
+    and the value 254 / 1 (an odd bit pattern only in bit 0 / in bits 1 .. 7).  All six planes against the oracle."""
+    rng = np.random.default_rng(5)
+    h, w = 200, 600                                      # bands of 64 rows (the last one 8 rows), column groups of 256 (the last one 88)
+    base = np.where(rng.random((h, w)) < 0.5, 0, 255).astype(np.uint8)
+    base[40:50, 100:400] = 255; base[120:140, :] = 0
+    spots = [(0, 0, 128), (37, 300, 7), (63, 255, 254), (64, 256, 1), (61, 10, 200), (66, 511, 100), (127, 259, 3), (130, 252, 77),
+             (191, 599, 254), (199, 599, 128), (199, 0, 1), (192, 512, 129), (100, 255, 126), (2, 257, 64)]
+    det = Detector(0, 4, w, h)
+    _blur_planes_match(det, [base])                      # no stray pixel: every band stays in the two-valued mode
+    for k in range(0, len(spots), 4):
+        imgs = []
+        for (y, x, v) in spots[k:k + 4]:
+            im = base.copy(); im[y, x] = v
+            imgs.append(im)
+        _blur_planes_match(det, imgs)
+    det.close()
+
+
 def test_plain_rounding_gaussian_taps_use_the_integer_kernels():
     """gauss_kernel_mode = 1 can give tap sums of 257, outside the float kernel's exactness condition: the
     integer kernels take over and still match the oracle."""
