@@ -22,6 +22,8 @@ constexpr int EB_CAP = EB * EB;  // worst case: every pixel of a bin is an edge
 constexpr int VRING = 192;            // per-wave item ring of k_vote_centres: < 64 waiting + <= 128 new per round
 constexpr int EBB_X = 4, EBB_Y = 2;   // bins per k_edge_bins workgroup (128 x 64 pixels)
 
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+
 // Sobel 3x3 with BORDER_REPLICATE at one pixel of a single-channel plane.
 __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitch, int w, int h, int x, int y, int& dx, int& dy)
 {
@@ -165,7 +167,8 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
     auto step = [&]() {
         if ((unsigned)x < xl && (unsigned)y < yl) {
             const unsigned ty = (unsigned)y >> 10;
-            atomicAdd(&s_acc[(ty & 63u) * (unsigned)VASTR + ((unsigned)x >> 10)], (unsigned)y >= (64u << 10) ? 0x10000u : 1u);
+            // the half of the dword: rows 64 .. 127 are bit 16 of y (y < 128 << 10 here); max(y & 0x10000, 1) is 0x10000 / 1 in two instructions
+            atomicAdd(&s_acc[(ty & 63u) * (unsigned)VASTR + ((unsigned)x >> 10)], umax_((unsigned)y & 0x10000u, 1u));
         }
         x += sx; y += sy;
     };
