@@ -160,8 +160,8 @@ __device__ __forceinline__ void vote_walk64(const unsigned* __restrict__ ring, i
         const uint2 e = bin_ent[item & 0x7fffffffu];   // read a moment ago by the culling pass: an L1 / L2 hit
         sx = (int)(short)(e.y & 0xffffu); sy = (int)(short)(e.y >> 16);
         if (item >> 31) { sx = -sx; sy = -sy; }
-        x = (((int)(e.x & 0xffffu) - vx_lo + offx) << 10) + min_r * sx;
-        y = (((int)(e.x >> 16) - vy_lo + offy) << 10) + min_r * sy;
+        x = (((int)(e.x & 0xffffu) - vx_lo + offx) << 10) + __mul24(min_r, sx);
+        y = (((int)(e.x >> 16) - vy_lo + offy) << 10) + __mul24(min_r, sy);
     }
     const unsigned xl = (vx_n + (unsigned)offx) << 10, yl = (vy_n + (unsigned)offy) << 10;
     auto step = [&]() {
@@ -276,8 +276,10 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
                 const int exr = (int)(mine.x & 0xffffu) - vx_lo, eyr = (int)(mine.x >> 16) - vy_lo;
                 // the cells of direction +1 lie between the pixel and pixel + ((max_r * s) >> 10) on each axis (+-1 for the
                 // floor), those of direction -1 between the pixel and pixel + ((-max_r * s) >> 10)
-                const int dxp = (max_r * sxv) >> 10, dyp = (max_r * syv) >> 10;
-                const int dxn = (-max_r * sxv) >> 10, dyn = (-max_r * syv) >> 10;
+                // (24-bit multiplies: |s| <= 1024 and the radius is far below 2^23; v_mul_lo_u32 is quarter rate)
+                const int px = __mul24(max_r, sxv), py = __mul24(max_r, syv);
+                const int dxp = px >> 10, dyp = py >> 10;
+                const int dxn = (-px) >> 10, dyn = (-py) >> 10;
                 reach_p = exr + imax(dxp, 0) + 1 >= 0 && exr + imin(dxp, 0) - 1 < (int)vx_n &&
                           eyr + imax(dyp, 0) + 1 >= 0 && eyr + imin(dyp, 0) - 1 < (int)vy_n;
                 reach_n = exr + imax(dxn, 0) + 1 >= 0 && exr + imin(dxn, 0) - 1 < (int)vx_n &&
