@@ -461,7 +461,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         const int rx = cdiv(wmax, 256), ry = cdiv(hmax, 4);            // row kernels: 256 x 4 pixels per workgroup
         const int fx = cdiv(wmax, FT_W), fy = cdiv(hmax, FT_H);        // 64 x 32 tiles
         const int mx = cdiv(wmax, MT_W), my = cdiv(hmax, MT_H);        // 56 x 72 tiles
-        const int ebx = cdiv(wmax, EBB_X * EB), eby = cdiv(hmax, EBB_Y * EB);      // 128 x 64 (4 x 2 edge bins)
+        const int ebx = cdiv(wmax, EBB_X * EB), eby = cdiv(hmax, EBB_Y * EB);      // 128 x 32 (4 x 1 edge bins)
         const int vx = cdiv(wmax, VT), vy = cdiv(hmax, VT);            // 126 x 126 accumulator cells
         const dim3 g_row((unsigned)rx * ry * nb), g_f((unsigned)fx * fy * nb), g_m((unsigned)mx * my * nb);
 
@@ -514,7 +514,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;
         I2S_SEG(8);
-        hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), b256, 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
+        hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), dim3(EBT), 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
                            ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
         I2S_SEG(9);
         // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled

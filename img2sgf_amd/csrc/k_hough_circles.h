@@ -20,7 +20,10 @@ constexpr int VTHREADS = 512;
 constexpr int EB = 32;           // edge bins: EB x EB pixel cells
 constexpr int EB_CAP = EB * EB;  // worst case: every pixel of a bin is an edge
 constexpr int VRING = 192;            // per-wave item ring of k_vote_centres: < 64 waiting + <= 128 new per round
-constexpr int EBB_X = 4, EBB_Y = 2;   // bins per k_edge_bins workgroup (128 x 64 pixels)
+constexpr int EBB_X = 4, EBB_Y = 1;   // bins per k_edge_bins workgroup (128 x 32 pixels)
+// threads, rows per load round, 16-byte loads per thread.  Measured (us per diagram): 256 threads on 128 x 64 pixels 4.47, on 128 x 32: 5.33, on
+// 128 x 128: 6.2; 128 threads on 128 x 32 (the same two loads per thread, twice the workgroups in flight): 4.27; 64 threads: 5.28
+constexpr int EBT = 128, EB_RPI = EBT / 8, EB_NLD = EBB_Y * EB / EB_RPI;
 
 __device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
 
@@ -42,13 +45,13 @@ __device__ __forceinline__ void sobel_at(const uint8_t* __restrict__ p, int pitc
 //   .x = x | y << 16,  .y = (sx & 0xffff) | sy << 16
 // with (sx, sy) = cvRound(d * 1024 / |d|) of its Sobel gradient d (hough.cpp HoughCirclesAccumInvoker), stored in the
 // bin of its 32x32-pixel cell.  The vote kernel then streams only the bins within reach of its accumulator tile.
-// grid (ceil(bins_x / EBB_X) * ceil(bins_y / EBB_Y) * nb * NVAR), block 256 (32 pixels per thread).
+// grid (ceil(bins_x / EBB_X) * ceil(bins_y / EBB_Y) * nb * NVAR), block EBT (32 pixels per thread).
 // bin_cnt[(bv * g.bins) + by * g.bw + bx], bin_ent[... * EB_CAP + k].
-__global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ desc, Geo g,
+__global__ __launch_bounds__(EBT) void k_edge_bins(const ImgDesc* __restrict__ desc, Geo g,
                                                    const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
                                                    uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt, int gx, int gy)
 {
-    // one block = 4 x 2 bins (128 x 64 pixels); two 16-byte map loads per thread, both in flight together (the kernel is
+    // one block = 4 x 1 bins (128 x 32 pixels); two 16-byte map loads per thread, both in flight together (the kernel is
     // latency-bound: load -> compact -> gather -> store).  Edge positions are first compacted into an LDS list (13-bit
     // tile-local coordinates) so that the gradient work (8 neighbour loads, sqrt, 2 divides) is spread evenly over the
     // block instead of serialising inside the few threads whose pixels lie on a line.
@@ -72,15 +75,15 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
     {
         const int ly = tid >> 3, c16 = (tid & 7) * 16;
         const int xs = x0 + c16;
-        uint4 m16[EBB_Y];
+        uint4 m16[EB_NLD];
 #pragma unroll
-        for (int r = 0; r < EBB_Y; r++) {
-            const int y = y0 + ly + r * EB;
+        for (int r = 0; r < EB_NLD; r++) {
+            const int y = y0 + ly + r * EB_RPI;
             m16[r] = make_uint4(0u, 0u, 0u, 0u);
             if (y < h && xs < w) m16[r] = *reinterpret_cast<const uint4*>(map + rowoff(y, g.pitch) + xs);
         }
 #pragma unroll
-        for (int r = 0; r < EBB_Y; r++) {
+        for (int r = 0; r < EB_NLD; r++) {
             const unsigned mw[4] = {m16[r].x, m16[r].y, m16[r].z, m16[r].w};
 #pragma unroll
             for (int d = 0; d < 4; d++) {
@@ -91,14 +94,14 @@ __global__ __launch_bounds__(256) void k_edge_bins(const ImgDesc* __restrict__ d
                 for (int q = 0; q < 4; q++) {
                     const int lx = c16 + 4 * d + q;
                     if (x0 + lx < w && ((m4 >> (8 * q)) & 0xffu) == 2u)
-                        s_list[atomicAdd(&s_nl, 1)] = (unsigned short)(lx | ((ly + r * EB) << 7));
+                        s_list[atomicAdd(&s_nl, 1)] = (unsigned short)(lx | ((ly + r * EB_RPI) << 7));
                 }
             }
         }
     }
     __syncthreads();
     const int nl = s_nl;
-    for (int i = tid; i < nl; i += 256) {
+    for (int i = tid; i < nl; i += EBT) {
         const int le = s_list[i];
         const int lx = le & 127, lyy = le >> 7;
         const int x = x0 + lx, y = y0 + lyy;
