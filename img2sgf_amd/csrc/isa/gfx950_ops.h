@@ -59,6 +59,9 @@ __device__ __forceinline__ void bl_bstore(BlBuf b, int row_off, unsigned off, un
 #define BL_CONSUME(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define BL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Placed inside a wave-uniform `if`: keeps it a BRANCH.  Left alone the compiler if-converts small bodies into "compute both, select"
+// (three v_perm + three v_cndmask per row in every wavefront for a border fix only the image's edge columns need).
+#define BL_KEEP_BRANCH() asm volatile("; uniform branch kept")
 // a value the optimiser cannot see through (keeps sign-mask arithmetic from being folded back into compare + select)
 __device__ __forceinline__ int opaque_vgpr(int d) { asm("" : "+v"(d)); return d; }
 

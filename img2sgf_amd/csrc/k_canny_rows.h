@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
             }
             unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E), Mf = M;
             if (fix) {
+                BL_KEEP_BRANCH();
                 const unsigned l2 = __builtin_amdgcn_perm(M, L, sL), m2 = __builtin_amdgcn_perm(M, L, sM), r2 = __builtin_amdgcn_perm(R, M, sR);
                 L = l2; Mf = m2; R = r2;
             }

@@ -18,6 +18,7 @@ struct BlBuf { uint8_t* p; };
 static inline BlBuf bl_buf(const void* p) { return BlBuf{const_cast<uint8_t*>(static_cast<const uint8_t*>(p))}; }
 static inline unsigned bl_bload(BlBuf b, int row_off, unsigned off) { unsigned v; memcpy(&v, b.p + row_off + off, 4); return v; }
 static inline void bl_bstore(BlBuf b, int row_off, unsigned off, unsigned v) { memcpy(b.p + row_off + off, &v, 4); }
+#define BL_KEEP_BRANCH() do {} while (0)
 #define BL_CONSUME(a, b) do { } while (0)
 #define BL_SCHED_FENCE() do { } while (0)
 static inline int opaque_vgpr(int d) { return d; }
