@@ -177,7 +177,10 @@ def main():
     # sanity: every rank holds the whole table, and the boards this rank produced equal the generator's occupancy
     assert allb.shape == (total, 384)
     mine = allb[lo:hi]
-    ok = bool((mine[:, :361].reshape(-1, 19, 19) == occs).all())
+    # ... or, for the handful of seeds whose diagram the reference's algorithm itself reads differently (synth.algorithm_exceptions:
+    # 15634 is the only one below 32768), the algorithm's answer
+    want, exceptions = synth.expected_boards(range(lo, hi), occs)
+    ok = bool((mine[:, :361].reshape(-1, 19, 19) == want).all())
     if use_dist:
         t = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -225,6 +228,8 @@ def main():
             "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU (BASELINE configs[%d]), "
                                    "device-resident, full hot path incl. board all-gather" % (B, 2 if world == 1 else 3),
                        "pass_size": pass_size, "streams": args.streams, "boards_match_generator": ok,
+                       "generator_exceptions_rank0": exceptions,
+                       "opencv_switches": dict(params.switch_set(), restates="OpenCV 4.3 .. 4.5.1 (package default, DESIGN.md 2a)"),
                        "rccl_ranks": world if use_dist else 0,
                        "allgather": "ncclAllGather of device-resident records through the C ABI" if use_dist else "single process: none",
                        "allgather_in_place": bool(gather.in_place()) if gather is not None else None},

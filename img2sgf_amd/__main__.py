@@ -24,13 +24,16 @@ def main(argv=None):
     ap.add_argument("--threshold", type=int, default=0, help="Hough-lines threshold (0 = choose_threshold)")
     ap.add_argument("--black-threshold", type=int, default=128)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--opencv", metavar="VERSION", help="restate this OpenCV release's arithmetic (e.g. 4.2.0, 4.8.1); default: the "
+                    "package defaults = OpenCV 4.3 .. 4.5.1 (Params.opencv_switches)")
     args = ap.parse_args(argv)
     inputs, out_single = args.inputs, None
     if len(inputs) == 2 and inputs[1].lower().endswith(".sgf") and not args.outdir:
         inputs, out_single = inputs[:1], inputs[1]
     import numpy as np
     params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
-                             contrast=args.contrast, brightness=args.brightness, schedule=True)
+                             contrast=args.contrast, brightness=args.brightness, schedule=True,
+                             **(pipeline.Params.opencv_switches(args.opencv) if args.opencv else {}))
     # Huffman-coded JPEGs (sequential or progressive) are decoded on the GPU straight from the file bytes (bit-exact with
     # Pillow's decoder); anything else (PNG, CMYK JPEG, ...) is opened with Pillow as the reference does (img2sgf.py:651).  Rotate / crop / contrast /
     # brightness run on the GPU either way.

@@ -145,7 +145,7 @@ extern "C" void i2s_default_params(i2s_params* p)
     p->line_threshold = 0; p->black_threshold = 128;
     p->align_x = I2S_ALIGN_LEFT; p->align_y = I2S_ALIGN_TOP;
     p->min_grid_spacing = 10; p->big_space_ratio = 1.6; p->angle_tolerance_deg = 1.0;
-    p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 0; p->inputs_on_device = 0; p->schedule = 0; p->jpeg_entropy_device = 1;
+    p->grey_shift = 15; p->gauss_kernel_mode = 0; p->houghlines_numangle_mode = 1; p->inputs_on_device = 0; p->schedule = 0; p->jpeg_entropy_device = 1;
     p->contrast = -1; p->brightness = -1;
 }
 

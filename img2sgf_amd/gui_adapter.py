@@ -17,9 +17,17 @@ import numpy as np
 from . import pipeline, preprocess
 
 
-def install(m, detector=None, lib=None):
-    """Patch reference module `m` in place.  Returns the Detector in use."""
-    state = {"det": detector, "lib": lib}
+def install(m, detector=None, lib=None, opencv=None):
+    """Patch reference module `m` in place.  Returns the adapter's state (state["det"] = the Detector in use).
+
+    opencv: the OpenCV release whose arithmetic the GPU path restates (Params.opencv_switches).  None = the release of the cv2
+    the reference itself imported (`m.cv.__version__`, which it logs at img2sgf.py:1246) -- the patched application then answers
+    as it did before the patch -- and the package defaults where that is not a version string."""
+    if opencv is None:
+        v = getattr(getattr(m, "cv", None), "__version__", None)
+        opencv = v if isinstance(v, str) and v[:1].isdigit() else None
+    switches = pipeline.Params.opencv_switches(opencv) if opencv else {}
+    state = {"det": detector, "lib": lib, "opencv": opencv, "switches": switches}
 
     def _detector(w, h):
         d = state["det"]
@@ -34,7 +42,8 @@ def install(m, detector=None, lib=None):
             canny_lo=int(m.edge_min.get()), canny_hi=int(m.edge_max.get()),      # img2sgf.py:163
             line_threshold=int(m.threshold.get()),                               # :259
             black_threshold=int(m.black_stone_threshold),                        # :515, 541
-            alignment=(int(m.board_alignment[0]), int(m.board_alignment[1])))    # :543
+            alignment=(int(m.board_alignment[0]), int(m.board_alignment[1])),    # :543
+            **switches)
 
     def _publish_board(det):
         m.detected_board = det.detected_board

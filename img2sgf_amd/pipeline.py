@@ -37,13 +37,36 @@ class Params:
     min_grid_spacing: float = 10       # :54
     big_space_ratio: float = 1.6       # :55
     angle_tolerance: float = 1.0       # :52 (degrees)
-    grey_shift: int = 15               # OpenCV-version switches
-    gauss_kernel_mode: int = 0
-    houghlines_numangle_mode: int = 0
+    # OpenCV-version switches.  The reference pins no OpenCV version; the defaults restate OpenCV 4.3 .. 4.5.1 (2020, the
+    # year the reference was written: DESIGN.md 2a has the evidence); Params.for_opencv(cv2.__version__) gives the set of any release.
+    grey_shift: int = 15               # 15: OpenCV 4.x coefficients | 14: 3.x
+    gauss_kernel_mode: int = 0         # 0: 8-bit taps diffused to sum 256 (>= 4.3 / 3.4.10) | 1: each tap rounded on its own (4.0 - 4.2)
+    houghlines_numangle_mode: int = 1  # 1: cvRound(range / theta) angles (<= 4.5.1) | 0: floor(range / theta) + 1 (>= 4.5.2)
     contrast: Optional[int] = None     # 0..100: ImageEnhance.Contrast on the device (img2sgf.py:141-144); None = input is already enhanced
     brightness: Optional[int] = None   # 0..100: ImageEnhance.Brightness on the device (:146-149)
     schedule: bool = False             # ragged batches larger than one device pass: form the passes over images sorted by area
     jpeg_entropy_device: int = 1       # detect_jpeg, Huffman decoding: 0 host threads, 1 sequential files on the device, 2 all on the device
+
+    @staticmethod
+    def opencv_switches(version: str) -> dict:
+        """The three version switches for an OpenCV release string such as cv2.__version__ ("4.2.0", "4.8.1.78", "3.4.9").
+        Best knowledge of OpenCV's history, unpinned like the rest of rows a2-a8 (no cv2 in the build image):
+        BGR2GRAY went from 14-bit to 15-bit coefficients with 4.0; GaussianBlur's 8-bit taps are error-diffused to sum 256 since
+        4.3.0 / 3.4.10; HoughLines counts its angles with floor(..) + 1 since 4.5.2 / 3.4.14."""
+        v = tuple(int("".join(ch for ch in part if ch.isdigit()) or 0) for part in (version.split(".") + ["0", "0"])[:3])
+        three = v[0] < 4
+        return dict(grey_shift=14 if three else 15,
+                    gauss_kernel_mode=0 if (v >= (4, 3, 0) or (three and v >= (3, 4, 10))) else 1,
+                    houghlines_numangle_mode=0 if (v >= (4, 5, 2) or (three and v >= (3, 4, 14))) else 1)
+
+    @classmethod
+    def for_opencv(cls, version: str, **kwargs):
+        """Params whose version switches restate the given OpenCV release (see opencv_switches)."""
+        return cls(**dict(cls.opencv_switches(version), **kwargs))
+
+    def switch_set(self) -> dict:
+        return dict(grey_shift=self.grey_shift, gauss_kernel_mode=self.gauss_kernel_mode,
+                    houghlines_numangle_mode=self.houghlines_numangle_mode)
 
     def to_c(self, inputs_on_device=False):
         p = I2sParams()

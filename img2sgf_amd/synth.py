@@ -148,3 +148,33 @@ def synth_batch_torch(seeds, device="cpu"):
     x0, y0 = g.origin_x - g.pitch // 2, g.origin_y - g.pitch // 2
     out[:, y0:y0 + N * g.pitch, x0:x0 + N * g.pitch] = mosaic
     return out, occs
+
+
+# ---- what the reference's algorithm makes of a seed -------------------------------------------------------------------
+_EXCEPTIONS = None
+
+
+def algorithm_exceptions():
+    """{seed: 19 x 19 board} for the seeds (searched: 0 .. 65535) whose board BY THE REFERENCE'S ALGORITHM is not the generator's
+    occupancy -- e.g. seed 15634: 18 stones on the 19 points of the last column hide its grid line, HoughLines finds 18 vertical
+    clusters, the board comes out 18 x 19.  Data written by tests/golden/make_synth_exceptions.py from the oracle's answers."""
+    global _EXCEPTIONS
+    if _EXCEPTIONS is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_exceptions.json")) as f:
+            _EXCEPTIONS = {int(s): np.array(e["board"], np.uint8) for s, e in json.load(f)["seeds"].items()}
+    return _EXCEPTIONS
+
+
+def expected_boards(seeds, occs):
+    """The boards a correct run of the hot path returns for `seeds`: the generator's occupancies `occs` (B, 19, 19), with the
+    algorithm's own answer substituted for the few seeds of algorithm_exceptions().  Returns (boards, exception seeds in range)."""
+    exc = algorithm_exceptions()
+    want = np.array(occs, np.uint8, copy=True)
+    hit = []
+    for k, s in enumerate(seeds):
+        if int(s) in exc:
+            want[k] = exc[int(s)]
+            hit.append(int(s))
+    return want, hit

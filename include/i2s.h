@@ -116,10 +116,11 @@ typedef struct i2s_params {
     double  min_grid_spacing;          /* 10                 :54 */
     double  big_space_ratio;           /* 1.6                :55 */
     double  angle_tolerance_deg;       /* 1.0                :52 */
-    /* OpenCV-version switches; defaults = current 4.x */
-    int32_t grey_shift;                /* 15 (4.x) | 14 (3.x) */
-    int32_t gauss_kernel_mode;         /* 0 = error-diffused taps summing to 256 | 1 = plain rounding */
-    int32_t houghlines_numangle_mode;  /* 0 = floor+1 with pi-wrap fix (current) | 1 = cvRound (legacy) */
+    /* OpenCV-version switches.  The reference pins no OpenCV version (it only logs cv.__version__,
+     * img2sgf.py:1246); the defaults restate OpenCV 4.3 .. 4.5.1, the releases of the year it was written. */
+    int32_t grey_shift;                /* 15 (4.x, default) | 14 (3.x) */
+    int32_t gauss_kernel_mode;         /* 0 = error-diffused taps summing to 256 (>= 4.3, default) | 1 = plain rounding (4.0 - 4.2) */
+    int32_t houghlines_numangle_mode;  /* 1 = cvRound(range / theta) angles (<= 4.5.1, default) | 0 = floor(..) + 1 with the pi-wrap fix (>= 4.5.2) */
     int32_t inputs_on_device;          /* 1: img[] are device pointers, read IN PLACE (no copy): a single-channel image with 4-byte
                                           aligned rows and a width that is a multiple of 4 also serves as its own grey plane: it must stay valid and unchanged until
                                           the next detect call if i2s_classify_batch / i2s_fetch_plane(GREY) are used on it;

@@ -64,7 +64,11 @@ def _u8(a):
 
 
 # Version switches; defaults = "current OpenCV 4.x".
-DEFAULT_COMPAT = dict(grey_shift=15, gauss_kernel_mode=0, houghlines_numangle=0)
+# The defaults restate OpenCV 4.3 .. 4.5.1 (the reference is dated March 2020 and its own fixtures only give sane
+# boards under the HoughLines angle count of those releases); the product's Params defaults are the same set.
+DEFAULT_COMPAT = dict(grey_shift=15, gauss_kernel_mode=0, houghlines_numangle=1)
+# The switch set tests/golden/oracle_stage_digests.json is written under (its "alt" entries hold the other value of each switch)
+DIGEST_COMPAT = dict(grey_shift=15, gauss_kernel_mode=0, houghlines_numangle=0)
 
 
 def bgr2gray(img, grey_shift=15):

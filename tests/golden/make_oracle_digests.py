@@ -21,7 +21,7 @@ from oracle import cv_oracle as cvo, glue, pipeline as opipe, stage_digests as s
 
 
 def entry(img):
-    r = opipe.process_image(img)
+    r = opipe.process_image(img, compat=cvo.DIGEST_COMPAT)
     e = {"input": sd.sha(img, np.uint8), "shape": list(img.shape), "threshold": int(r["threshold"]), "stages": sd.stage_digests(r),
          "sgf": r["sgf"]}
     alt = {}
@@ -38,7 +38,7 @@ def entry(img):
 
 def build(names=None):
     doc = {"what": "oracle/ outputs per OpenCV call site (img2sgf.py line numbers in the keys); sha256[:32] of str(shape) + bytes",
-           "switches": dict(cvo.DEFAULT_COMPAT), "inputs": {}}
+           "switches": dict(cvo.DIGEST_COMPAT), "inputs": {}}
     for name, img in sd.inputs(os.path.join(HERE, "test_images")):
         if names is None or name in names:
             doc["inputs"][name] = entry(img)

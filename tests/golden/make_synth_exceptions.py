@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Writes img2sgf_amd/synth_exceptions.json (data beside the generator it describes): the seeds of the synthetic workload (img2sgf_amd.synth, BASELINE configs[2] / [3])
+whose board -- by the REFERENCE'S ALGORITHM, as the oracle runs it -- is not the generator's occupancy, with the board the algorithm
+does produce.  Example: seed 15634 has stones on 18 of the 19 points of its last column, the column's grid line disappears under
+them, HoughLines finds 18 vertical clusters and the board comes out 18 x 19 (img2sgf.py:420-445 has no way to know).
+
+The candidate seeds come from the GPU path (tools/synth_mismatches.py over seeds 0 .. 65535, profiles/r04_synth_mismatches.json);
+this script confirms each with the oracle and records the oracle's answer.  bench.py and tests/test_gpu_full_size.py accept exactly
+these boards for exactly these seeds and the generator's occupancy for every other seed.
+
+    python tests/golden/make_synth_exceptions.py 15634 46384 51849 55399 60431
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import numpy as np  # noqa: E402
+
+from img2sgf_amd import synth  # noqa: E402
+from oracle import pipeline as opipe  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(HERE)), "img2sgf_amd", "synth_exceptions.json")
+
+
+def entry(seed):
+    img, occ = synth.synth_diagram(seed)
+    r = opipe.process_image(img, keep_planes=False)
+    assert r["board_ready"], seed
+    board = np.asarray(r["full_board"], np.uint8)
+    assert (board != occ).any(), "seed %d: the oracle recovers the generator's occupancy, not an exception" % seed
+    return {"hsize": int(r["hsize"]), "vsize": int(r["vsize"]), "n_black": int(r["num_black_stones"]),
+            "n_white": int(r["num_white_stones"]), "side_to_move": int(r["side_to_move"]),
+            "board": board.tolist(), "cells_differing": int((board != occ).sum())}
+
+
+if __name__ == "__main__":
+    seeds = [int(s) for s in sys.argv[1:]]
+    doc = {"what": "synthetic-workload seeds whose board by the reference's algorithm (oracle) differs from the generator's occupancy",
+           "searched": "seeds 0 .. 65535 (GPU path, tools/synth_mismatches.py), each confirmed here by the oracle",
+           "seeds": {str(s): entry(s) for s in seeds}}
+    with open(OUT, "w") as f:
+        json.dump(doc, f, sort_keys=True)
+    print("wrote", OUT, {s: (e["hsize"], e["vsize"], e["cells_differing"]) for s, e in doc["seeds"].items()})

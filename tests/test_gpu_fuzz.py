@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import parity
+import switches
 from helpers import GOLDEN
 from img2sgf_amd import synth
 from img2sgf_amd.pipeline import Detector, Params
@@ -58,7 +59,16 @@ def _random_image(rng):
     return img
 
 
-def _random_params(rng):
+def _random_params(rng, seed=0):
+    if seed % 3 == 2:
+        # every third seed: a non-default OpenCV-version switch set, with default or random other parameters
+        sw = switches.NAMES[(seed // 3) % len(switches.NAMES)]
+        if rng.random() < 0.5:
+            return switches.params(sw), dict(compat=switches.compat(sw))
+        p, okw = _random_params(rng, 0)
+        for k, v in switches.params_kwargs(sw).items():
+            setattr(p, k, v)
+        return p, dict(okw, compat=switches.compat(sw))
     if rng.random() < 0.35:
         return Params(), {}
     lo = int(rng.integers(5, 120))
@@ -80,7 +90,7 @@ N_SEEDS = int(os.environ.get("I2S_FUZZ_SEEDS", 60))       # raise for a longer h
 def test_fuzz_against_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     imgs = [_random_image(rng) for _ in range(4)]
-    params, okw = _random_params(rng)
+    params, okw = _random_params(rng, seed)
     det = Detector(0, 4, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
     dets = det.detect_batch(imgs, params, full=True)
     over = [k for k, d in enumerate(dets) if d.status == 100]
@@ -97,7 +107,7 @@ def test_fuzz_against_oracle(seed):
                     or max(d["n_centers"] for d in dbg) > max(8192, det.max_w * det.max_h // 8)), "capacity status without a capacity being exceeded"
         imgs = [im for k, im in enumerate(imgs) if k not in over]
     if imgs:
-        parity.run_and_compare(det, imgs, params=params, internals=okw == {}, oracle_kwargs=okw)
+        parity.run_and_compare(det, imgs, params=params, internals=set(okw) <= {"compat"}, oracle_kwargs=okw)
     det.close()
 
 

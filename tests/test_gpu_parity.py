@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import parity
+import switches
 from helpers import GOLDEN, load_glue_golden, synth_grey
 from img2sgf_amd import synth
 from img2sgf_amd.pipeline import Detector, Params, board_to_sgf
@@ -88,24 +89,28 @@ def test_synthetic_1024_batch_multi_pass():
     det.close()
 
 
+@pytest.mark.parametrize("sw", switches.NAMES)
 @pytest.mark.parametrize("name", IMAGES)
-def test_reference_image(name):
-    """BASELINE configs[4]: the reference's 18 fixtures, Pillow pre-processing on the host, SGF byte-diff."""
+def test_reference_image(name, sw):
+    """BASELINE configs[4]: the reference's 18 fixtures, Pillow pre-processing on the host, every plane / list / record and the
+    SGF bytes against the oracle -- under every OpenCV-version switch set (tests/switches.py): the grey weights of
+    3.x on the colour fixtures, the plain-rounded Gaussian taps (integer kernels), both HoughLines angle counts."""
     img = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", name))
     det = Detector(0, 1, img.shape[1], img.shape[0])
-    d = parity.run_and_compare(det, [img])[0]
+    d = parity.run_and_compare(det, [img], params=switches.params(sw), oracle_kwargs=dict(compat=switches.compat(sw)))[0]
     if name == "ex1.jpg":
-        assert d.sgf == EX1_SGF      # the reference's only recorded result (screenshot.jpg)
+        assert d.sgf == EX1_SGF      # the reference's only recorded result (screenshot.jpg), the same under every switch set
     det.close()
 
 
-def test_all_reference_images_one_mixed_batch():
+@pytest.mark.parametrize("sw", switches.NAMES)
+def test_all_reference_images_one_mixed_batch(sw):
     imgs = [opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", n)) for n in IMAGES]
     det = Detector(0, 6, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
-    boards = det.detect_batch(imgs, full=False)
+    boards = det.detect_batch(imgs, switches.params(sw), full=False)
     for n, img, b in zip(IMAGES, imgs, boards):
-        ref = opipe.process_image(img, keep_planes=False)
-        assert board_to_sgf(b) == ref["sgf"], n
+        ref = opipe.process_image(img, keep_planes=False, compat=switches.compat(sw))
+        assert board_to_sgf(b) == ref["sgf"], (n, sw)
     det.close()
 
 

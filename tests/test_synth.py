@@ -1,4 +1,6 @@
 """The synthetic workload generator: deterministic, and the batched torch renderer equals the numpy one bit for bit."""
+import os
+
 import numpy as np
 
 from img2sgf_amd import synth
@@ -17,3 +19,18 @@ def test_torch_renderer_matches_numpy():
     t, occs = synth.synth_batch_torch(seeds, "cpu")
     ref, occs_ref = synth.synth_batch(seeds)
     assert (t.numpy() == ref).all() and (occs == occs_ref).all()
+
+
+def test_algorithm_exceptions_are_what_the_oracle_answers():
+    """img2sgf_amd/synth_exceptions.json (the seeds whose board by the reference's algorithm is not the generator's occupancy) is
+    oracle-generated data: regenerate the first entry and compare."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_synth_exceptions as mk
+    exc = synth.algorithm_exceptions()
+    assert sorted(exc) == [15634, 46384, 51849, 55399, 60431]
+    e = mk.entry(15634)
+    assert (np.array(e["board"], np.uint8) == exc[15634]).all() and (e["hsize"], e["vsize"]) == (18, 19)
+    occs = np.stack([synth.occupancy(s) for s in (15633, 15634)])
+    want, hit = synth.expected_boards([15633, 15634], occs)
+    assert hit == [15634] and (want[0] == occs[0]).all() and (want[1] == exc[15634]).all()
