@@ -135,6 +135,9 @@ static inline int* vcount(i2s_ctx* c) { return c->d_counts + (size_t)2 * c->max_
 static inline int* overflow(i2s_ctx* c) { return c->d_counts + (size_t)3 * c->max_batch * NVAR; }
 static inline size_t counts_bytes(i2s_ctx* c) { return ((size_t)3 * c->max_batch * NVAR + c->max_batch) * sizeof(int); }
 
+#ifdef I2S_EXP_COUNT
+extern "C" void i2s_exp_counts(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(i2s::g_vp_count), 64); unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(i2s::g_vp_count), z, 64); }
+#endif
 extern "C" int i2s_abi_version(void) { return I2S_ABI_VERSION; }
 
 extern "C" void i2s_default_params(i2s_params* p)
@@ -518,6 +521,22 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                            ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
         I2S_SEG(9);
         // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
+        if (getenv("I2S_VOTE_OLD") == nullptr) {
+            static_assert(NVAR % 2 == 0, "k_vote_pairs pairs the HoughCircles inputs");
+            if (p->hc_max_radius - p->hc_min_radius + 1 == 30 && !getenv("I2S_VOTE_ROLLED"))
+                if (!getenv("I2S_VOTE_SPLIT"))
+                hipLaunchKernelGGL((k_vote_pairs<30, false>), dim3((unsigned)vx * vy * nb * (NVAR / 2)), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
+                                   ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                                   ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+                else
+                hipLaunchKernelGGL((k_vote_pairs<30, true>), dim3((unsigned)vx * vy * nb * (NVAR / 2)), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
+                                   ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                                   ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+            else
+                hipLaunchKernelGGL((k_vote_pairs<0, true>), dim3((unsigned)vx * vy * nb * (NVAR / 2)), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
+                                   ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                                   ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+        } else
         if (p->hc_max_radius - p->hc_min_radius + 1 == 30)
             hipLaunchKernelGGL((k_vote_centres<30>), dim3((unsigned)vx * vy * nb * NVAR), dim3(VTHREADS), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
                                ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),

@@ -370,6 +370,239 @@ __global__ __launch_bounds__(512) void k_vote_centres(const ImgDesc* __restrict_
 #undef I2S_CELL
 }
 
+// ---- round 4: two tiles per workgroup ------------------------------------------------------------------------------------
+// The vote kernel is bound by the vector instructions of its radius walk (profiles/r03_b_vote_experiments.txt: 74 % of its
+// instructions are walk steps, 10 vector + 4 scalar instructions each).  Two changes take 6 of the 10 out of most steps:
+//  * the two 16-bit halves of an LDS dword are the same tile cell of TWO HoughCircles inputs (variants 2p and 2p + 1 of one image)
+//    instead of two rows of one tile: the increment (1 or 0x10000) is a constant of the item -- it follows from which variant's
+//    bin list the record came from -- and the row index needs no "& 63".  A workgroup of 1024 threads (16 wavefronts) owns the
+//    pair: 128 x 129 dwords + 16 item rings = 78.5 KB, two workgroups per CU, the same 8 wavefronts per SIMD as before.
+//  * a ray is a straight segment and the tile's valid cells are a box, so an item whose first (min_r) and last (max_r) cells are
+//    both inside votes on EVERY step: such items (about six in ten) are collected apart and walked with no range test at all --
+//    address (4 instructions), atomic, two adds.  The others keep the per-step test.
+// Bit-exact by construction: the same (edge, direction, r) votes land in the same cells; only who walks them when has changed.
+constexpr int VPT = 1024, VPW = VPT / 64;
+#ifdef I2S_EXP_COUNT
+__device__ unsigned long long g_vp_count[8];
+#define VPC(i, n) do { if (lane == 0) atomicAdd(&g_vp_count[i], (unsigned long long)(n)); } while (0)
+#else
+#define VPC(i, n) do {} while (0)
+#endif
+#ifndef I2S_EXP_INLINE
+#define I2S_EXP_INLINE __forceinline__
+#endif
+#ifndef I2S_EXP_FULL
+#define I2S_EXP_FULL true
+#endif
+
+template <int NSTEPS, bool FULL>
+__device__ I2S_EXP_INLINE void vote_walk_pair(unsigned item, bool active, const uint2* __restrict__ bin_ent, unsigned ent_split,
+                                               int vx_lo, int vy_lo, unsigned vx_n, unsigned vy_n, int offx, int offy, int min_r,
+                                               int nsteps, unsigned* __restrict__ s_acc)
+{
+    if (active) {
+        const unsigned idx = item & 0x7fffffffu;
+        const uint2 e = bin_ent[idx];                      // read a moment ago by the culling pass: an L1 / L2 hit
+        int sx = (int)(short)(e.y & 0xffffu), sy = (int)(short)(e.y >> 16);
+        if (item >> 31) { sx = -sx; sy = -sy; }
+        // 22.10 fixed point relative to the LDS tile's first cell, as in vote_walk64
+        int x = (((int)(e.x & 0xffffu) - vx_lo + offx) << 10) + __mul24(min_r, sx);
+        int y = (((int)(e.x >> 16) - vy_lo + offy) << 10) + __mul24(min_r, sy);
+        const unsigned val = idx >= ent_split ? 0x10000u : 1u;
+        const unsigned xl = (vx_n + (unsigned)offx) << 10, yl = (vy_n + (unsigned)offy) << 10;
+        auto step = [&]() {
+            if (FULL || ((unsigned)x < xl && (unsigned)y < yl))
+                atomicAdd(&s_acc[((unsigned)y >> 10) * (unsigned)VASTR + ((unsigned)x >> 10)], val);
+            x += sx; y += sy;
+        };
+        if (NSTEPS > 0) {
+#pragma unroll
+            for (int st = 0; st < NSTEPS; st++) step();
+        } else {
+            for (int st = 0; st < nsteps; st++) step();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// grid (tiles_x * tiles_y * nb * NVAR / 2), block 1024.  Same outputs as k_vote_centres.
+template <int NSTEPS, bool SPLIT>
+__global__ __launch_bounds__(VPT) void k_vote_pairs(const ImgDesc* __restrict__ desc, Geo g,
+                                                    const uint2* __restrict__ bin_ent, const int* __restrict__ bin_cnt,
+                                                    int min_r, int max_r, int acc_thr,
+                                                    unsigned* __restrict__ cent_list, int* __restrict__ cent_count,
+                                                    int* __restrict__ dbg_acc, int gx, int gy)
+{
+    __shared__ unsigned s_acc[VL * VASTR];         // cell (cx, cy): dword cy * VASTR + cx; low half variant 2p, high half variant 2p + 1
+    __shared__ int s_ticket;
+    __shared__ unsigned s_ring[VPW][VRING];        // per wavefront: always-inside items from the bottom, the others from the top
+    __shared__ int s_fill[VPW][2];
+    const TileId tl = tile_of_block(gx, gy);
+    const int b = tl.z / (NVAR / 2), v0 = (tl.z % (NVAR / 2)) * 2;
+    const int w = desc[b].w, h = desc[b].h;
+    const int cx0 = tl.tx * VT, cy0 = tl.ty * VT;    // first interior cell
+    if (cx0 >= w || cy0 >= h) return;
+    const int tid = threadIdx.x;
+    const int bv = b * NVAR + v0;
+    for (int i = tid; i < VL * VASTR; i += VPT) s_acc[i] = 0;
+    if (tid == 0) s_ticket = VPW;                  // bins 0 .. 15 are taken by the waves' first round
+    __syncthreads();
+    const int lx0 = cx0 - 1, ly0 = cy0 - 1;
+    const int bx0 = imax(lx0 - max_r, 0) / EB, bx1 = imin(lx0 + VL - 1 + max_r, w - 1) / EB;
+    const int by0 = imax(ly0 - max_r, 0) / EB, by1 = imin(ly0 + VL - 1 + max_r, h - 1) / EB;
+    const int nbx = bx1 - bx0 + 1, nbin = nbx * (by1 - by0 + 1);      // per variant, <= 49; bins nbin .. 2 nbin - 1 are variant 2p + 1's
+    const int vx_lo = imax(lx0, 0), vy_lo = imax(ly0, 0);
+    const unsigned vx_n = (unsigned)(imin(lx0 + VL, w) - vx_lo), vy_n = (unsigned)(imin(ly0 + VL, h) - vy_lo);
+    const int offx = vx_lo - lx0, offy = vy_lo - ly0;
+    const int nsteps = max_r - min_r + 1;
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned ent_split = (unsigned)((size_t)(bv + 1) * g.bins * EB_CAP);     // first record index of variant 2p + 1
+    const int xl = (int)((vx_n + (unsigned)offx) << 10), yl = (int)((vy_n + (unsigned)offy) << 10);
+    int my_cnt_a = 0, my_cnt_b = 0, my_bin = 0;
+    if (lane < nbin) {
+        my_bin = (int)((size_t)bv * g.bins + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx));
+        my_cnt_a = bin_cnt[my_bin];
+        my_cnt_b = bin_cnt[my_bin + g.bins];
+    }
+    auto bin_of = [&](int q, int& n, const uint2*& ent) {      // q is wave-uniform
+        const int qq = q < nbin ? q : q - nbin;
+        n = q < nbin ? __builtin_amdgcn_readlane(my_cnt_a, qq) : __builtin_amdgcn_readlane(my_cnt_b, qq);
+        ent = bin_ent + ((size_t)__builtin_amdgcn_readlane(my_bin, qq) + (q < nbin ? 0 : (size_t)g.bins)) * EB_CAP;
+    };
+    int q = wave;
+    int n_cur = 0;
+    const uint2* ent_cur = bin_ent;
+    uint2 mine = make_uint2(0u, 0u);
+    if (q < 2 * nbin) {
+        bin_of(q, n_cur, ent_cur);
+        if (lane < n_cur) mine = ent_cur[lane];
+    }
+    unsigned* ring = s_ring[wave];
+    int fill_f = 0, fill_p = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    auto drain = [&]() {
+        while (fill_f >= 64) {
+            VPC(0, 1);
+            vote_walk_pair<NSTEPS, I2S_EXP_FULL>(ring[lane], true, bin_ent, ent_split, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+            const int rem = fill_f - 64;               // < 64
+            unsigned t0 = 0;
+            if (lane < rem) t0 = ring[64 + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rem) ring[lane] = t0;
+            fill_f = rem;
+            __builtin_amdgcn_wave_barrier();
+        }
+        while (fill_p >= 64) {
+            VPC(1, 1);
+            vote_walk_pair<NSTEPS, false>(ring[VRING - 1 - lane], true, bin_ent, ent_split, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+            const int rem = fill_p - 64;
+            unsigned t0 = 0;
+            if (lane < rem) t0 = ring[VRING - 1 - 64 - lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rem) ring[VRING - 1 - lane] = t0;
+            fill_p = rem;
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    while (q < 2 * nbin) {
+        int qn = 0;
+        if (lane == 0) qn = atomicAdd(&s_ticket, 1);
+        qn = __builtin_amdgcn_readlane(qn, 0);
+        int n_next = 0;
+        const uint2* ent_next = bin_ent;
+        uint2 mine_next = make_uint2(0u, 0u);
+        if (qn < 2 * nbin) {
+            bin_of(qn, n_next, ent_next);
+            if (lane < n_next) mine_next = ent_next[lane];
+        }
+        const unsigned ent_base = (unsigned)(ent_cur - bin_ent);
+        for (int k0 = 0; k0 < n_cur; k0 += 64) {
+            if (k0 > 0) { mine = make_uint2(0u, 0u); if (k0 + lane < n_cur) mine = ent_cur[k0 + lane]; }
+            // Per direction d = +1 / -1 and axis the ray's coordinates run monotonically from X0 + d min_r s to X0 + d max_r s: the ray can
+            // touch the tile only if that span meets [0, limit) on both axes (a superset: the per-step test decides), and it votes on
+            // every step if both ends lie inside on both axes.
+            bool in_p = false, in_n = false, all_p = false, all_n = false;
+            if (k0 + lane < n_cur) {
+                const int sxv = (int)(short)(mine.y & 0xffffu), syv = (int)(short)(mine.y >> 16);
+                const int X0 = ((int)(mine.x & 0xffffu) - vx_lo + offx) << 10, Y0 = ((int)(mine.x >> 16) - vy_lo + offy) << 10;
+                const int ax = __mul24(min_r, sxv), bx = __mul24(max_r, sxv), ay = __mul24(min_r, syv), by = __mul24(max_r, syv);
+                const int mnx = imin(ax, bx), mxx = imax(ax, bx), mny = imin(ay, by), mxy = imax(ay, by);
+                const int xlo_p = X0 + mnx, xhi_p = X0 + mxx, ylo_p = Y0 + mny, yhi_p = Y0 + mxy;
+                const int xlo_n = X0 - mxx, xhi_n = X0 - mnx, ylo_n = Y0 - mxy, yhi_n = Y0 - mny;
+                in_p = xhi_p >= 0 && xlo_p < xl && yhi_p >= 0 && ylo_p < yl;
+                in_n = xhi_n >= 0 && xlo_n < xl && yhi_n >= 0 && ylo_n < yl;
+                all_p = xlo_p >= 0 && xhi_p < xl && ylo_p >= 0 && yhi_p < yl;
+                all_n = xlo_n >= 0 && xhi_n < xl && ylo_n >= 0 && yhi_n < yl;
+            }
+            const unsigned item = ent_base + (unsigned)(k0 + lane);
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const bool in = d ? in_n : in_p, all = SPLIT && (d ? all_n : all_p);
+                const unsigned it = d ? (item | 0x80000000u) : item;
+                const unsigned long long mf = __ballot(all), mp = __ballot(in && !all);
+                if (all) ring[fill_f + __popcll(mf & below)] = it;
+                else if (in) ring[VRING - 1 - (fill_p + __popcll(mp & below))] = it;
+                fill_f += __popcll(mf); fill_p += __popcll(mp); VPC(4, __popcll(mf)); VPC(5, __popcll(mp)); VPC(6, 1);        // <= 63 + 63 + 64 entries: the two ends never meet
+                __builtin_amdgcn_wave_barrier();
+                drain();
+            }
+        }
+        q = qn; n_cur = n_next; ent_cur = ent_next; mine = mine_next;
+    }
+    // leftovers (< 64 per class and wavefront): walked as two lists over the sixteen rings, 64 items per wavefront
+    if (lane == 0) { s_fill[wave][0] = fill_f; s_fill[wave][1] = fill_p; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        int before = 0, r = 0, tot = 0;
+        const int gi = wave * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < VPW; k++) {
+            const int f = s_fill[k][c];
+            if (gi >= tot + f) { before = tot + f; r = k + 1; }
+            tot += f;
+        }
+        const int cnt = imin(imax(tot - wave * 64, 0), 64);
+        if (cnt > 0) {
+            VPC(2 + c, 1);
+            unsigned it = 0;
+            if (lane < cnt) it = c == 0 ? s_ring[r][gi - before] : s_ring[r][VRING - 1 - (gi - before)];
+            if (c == 0) vote_walk_pair<NSTEPS, I2S_EXP_FULL>(it, lane < cnt, bin_ent, ent_split, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+            else vote_walk_pair<NSTEPS, false>(it, lane < cnt, bin_ent, ent_split, vx_lo, vy_lo, vx_n, vy_n, offx, offy, min_r, nsteps, s_acc);
+        }
+    }
+    __syncthreads();
+    // centre candidates (as k_vote_centres): interior cells (tx, ty), 1 <= tx, ty <= VT; the two halves are two variants
+#define I2S_CELLP(cx, cy, hh) ((int)((s_acc[(cy) * VASTR + (cx)] >> ((hh) * 16)) & 0xffffu))
+    if (dbg_acc) {
+        for (int i = tid; i < VT * VT; i += VPT) {
+            const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
+            const int x = lx0 + tx, y = ly0 + ty;
+            if (x < w && y < h) {
+                dbg_acc[((size_t)bv * g.hmax + y) * g.pitch + x] = I2S_CELLP(tx, ty, 0);
+                dbg_acc[((size_t)(bv + 1) * g.hmax + y) * g.pitch + x] = I2S_CELLP(tx, ty, 1);
+            }
+        }
+    }
+    for (int i = tid; i < VT * VT; i += VPT) {
+        const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
+        const unsigned v2 = s_acc[ty * VASTR + tx];
+        if ((int)(v2 & 0xffffu) <= acc_thr && (int)(v2 >> 16) <= acc_thr) continue;
+        const int x = lx0 + tx, y = ly0 + ty;
+        if (x >= w || x < 1 || y >= h || y < 1) continue;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int a = hh ? (int)(v2 >> 16) : (int)(v2 & 0xffffu);
+            if (a <= acc_thr) continue;
+            if (a > I2S_CELLP(tx - 1, ty, hh) && a >= I2S_CELLP(tx + 1, ty, hh) && a > I2S_CELLP(tx, ty - 1, hh) && a >= I2S_CELLP(tx, ty + 1, hh)) {
+                const int k = atomicAdd(&cent_count[bv + hh], 1);
+                if (k < g.cent_cap) cent_list[(size_t)(bv + hh) * g.cent_cap + k] = (unsigned)x | ((unsigned)y << 16);
+            }
+        }
+    }
+#undef I2S_CELLP
+}
+
 // Sort key of an estimated circle; ascending key order == OpenCV's cmpAccum order
 // (accum desc, radius desc, x asc, y asc).  s = upbin + j of the radius histogram scan (radius = s/20 + min_r).
 __device__ __forceinline__ unsigned long long est_key(int acc, int s, int x, int y)

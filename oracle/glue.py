@@ -28,8 +28,10 @@ def choose_threshold(w, h):
     return int(min(max(t, 20), 200))
 
 
-def find_lines(circles_removed, threshold, horizontal, numangle_mode=0):
-    """img2sgf.py:230-255 -> (n,1) float32 rho column, or [] when nothing is found."""
+def find_lines(circles_removed, threshold, horizontal, numangle_mode=None):
+    """img2sgf.py:230-255 -> (n,1) float32 rho column, or [] when nothing is found.  numangle_mode None = the default switch set."""
+    if numangle_mode is None:
+        numangle_mode = cvo.DEFAULT_COMPAT["houghlines_numangle"]
     theta = math.pi / 180.0
     if horizontal:
         lines = cvo.hough_lines(circles_removed, 1, theta, threshold,

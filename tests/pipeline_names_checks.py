@@ -91,6 +91,6 @@ def check_find_lines(det):
     import math
     from oracle import cv_oracle as cvo
     dlt = math.pi / 180 * 1.4
-    want = cvo.hough_lines(removed, 1, math.pi / 180.0, thr, math.pi / 2 - dlt, math.pi / 2 + dlt)
+    want = cvo.hough_lines(removed, 1, math.pi / 180.0, thr, math.pi / 2 - dlt, math.pi / 2 + dlt, cvo.DEFAULT_COMPAT["houghlines_numangle"])
     want = np.zeros(0, np.float32) if want is None else want[:, 0, 0]
     np.testing.assert_array_equal(np.asarray(hl2, np.float32).reshape(-1), want)
