@@ -91,7 +91,7 @@ EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s
            "i2s_comm_unique_id", "i2s_comm_create", "i2s_comm_destroy", "i2s_comm_last_error", "i2s_comm_shard", "i2s_comm_all",
            "i2s_set_board_sink", "i2s_allgather_boards",
            "i2s_set_profiling", "i2s_last_kernel_timing", "i2s_kernel_timing_name"]
-NSEG = 15
+NSEG = 14
 ABI_VERSION = 2
 COMM_ID_BYTES = 128
 

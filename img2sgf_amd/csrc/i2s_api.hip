@@ -93,8 +93,6 @@ struct i2s_ctx {
     int* d_mflags = nullptr;     // [nb][bands_y][bands_x] k_median57_bin: the band holds a pixel other than 0 / 255
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
-    unsigned* d_rl_items = nullptr;      // per (image, variant, accumulator tile, class): RL_CAP ray items (k_ray_lists)
-    int* d_rl_cnt = nullptr;
     int* d_lacc = nullptr;
     int lrow = 0;
     i2s_result* d_res = nullptr;
@@ -116,7 +114,7 @@ struct i2s_ctx {
 // segments of i2s_last_kernel_timing, in launch order
 static const char* const kSegName[I2S_NSEG] = {
     "k_grey", "k_median57_bin", "k_blur", "k_median57", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
-    "k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_ray_lists", "k_vote_centres", "k_radius",
+    "k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
     "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
 #define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
 
@@ -137,9 +135,6 @@ static inline int* vcount(i2s_ctx* c) { return c->d_counts + (size_t)2 * c->max_
 static inline int* overflow(i2s_ctx* c) { return c->d_counts + (size_t)3 * c->max_batch * NVAR; }
 static inline size_t counts_bytes(i2s_ctx* c) { return ((size_t)3 * c->max_batch * NVAR + c->max_batch) * sizeof(int); }
 
-#ifdef I2S_EXP_COUNT
-extern "C" void i2s_exp_counts(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(i2s::g_vp_count), 64); unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(i2s::g_vp_count), z, 64); }
-#endif
 extern "C" int i2s_abi_version(void) { return I2S_ABI_VERSION; }
 
 extern "C" void i2s_default_params(i2s_params* p)
@@ -182,7 +177,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_rl_items, ctx->d_rl_cnt, ctx->d_weak, ctx->d_chg, ctx->d_hmark, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_hmark, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob, ctx->h_coef.p};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -207,8 +202,6 @@ static int create_impl(i2s_ctx* ctx)
     g.slot = (long long)g.pitch * g.hmax;
     g.bw = (ctx->max_w + EB - 1) / EB;
     g.bins = g.bw * ((ctx->max_h + EB - 1) / EB);
-    g.vtx = (ctx->max_w + VT - 1) / VT;
-    g.vtiles = g.vtx * ((ctx->max_h + VT - 1) / VT);
     g.tw = (ctx->max_w + CT_W - 1) / CT_W;
     g.tiles = g.tw * ((ctx->max_h + CT_H - 1) / CT_H);
     {
@@ -250,8 +243,6 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_vcirc, nb * NVAR * g.vcirc_cap * 3 * sizeof(float)));
     I2S_HIP(hipMalloc(&ctx->d_bin_cnt, nb * NVAR * g.bins * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_bin_ent, nb * NVAR * g.bins * EB_CAP * sizeof(uint2)));
-    I2S_HIP(hipMalloc(&ctx->d_rl_cnt, nb * NVAR * g.vtiles * 2 * sizeof(int)));
-    I2S_HIP(hipMalloc(&ctx->d_rl_items, nb * NVAR * g.vtiles * 2 * RL_CAP * sizeof(unsigned)));
     ctx->lrow = (2 * (ctx->max_w + ctx->max_h) + 1 + 15) / 16 * 16;
     I2S_HIP(hipMalloc(&ctx->d_lacc, nb * LROWS * ctx->lrow * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_res, nb * sizeof(i2s_result)));
@@ -460,7 +451,6 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, (2 * HYST_MAX_PASSES + 4) * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 0), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(worklist(ctx, 1), 0, sizeof(int), st));
-        I2S_HIP(hipMemsetAsync(ctx->d_rl_cnt, 0, (size_t)nb * NVAR * g.vtiles * 2 * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_mflags, 0, (size_t)nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
@@ -529,42 +519,23 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_SEG(9);
         // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
         {
-            static_assert(NVAR % 2 == 0, "the vote kernels pair the HoughCircles inputs");
-            const char* mode = getenv("I2S_VOTE");              // experiments: "pairs" = the tile-major kernel of round 4a
+            static_assert(NVAR % 2 == 0, "k_vote_centres pairs the HoughCircles inputs");
             const unsigned vgrid = (unsigned)vx * vy * nb * (NVAR / 2);
-            const bool r30 = p->hc_max_radius - p->hc_min_radius + 1 == 30;     // the reference's radius range: unrolled walk
-            if (mode && !strcmp(mode, "pairs")) {
-                I2S_SEG(10);
-                if (r30)
-                    hipLaunchKernelGGL((k_vote_pairs<30, false>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
-                                       p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
-                                       ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
-                else
-                    hipLaunchKernelGGL((k_vote_pairs<0, false>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
-                                       p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
-                                       ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
-            } else {
-                {
-                    const unsigned nunits = (unsigned)(cdiv(ebx, RL_K) * eby * nb * NVAR);
-                    hipLaunchKernelGGL(k_ray_lists, dim3((unsigned)cdiv((int)nunits, RL_WPB)), dim3(RLT * RL_WPB), 0, st, ctx->d_desc, g, ctx->d_bin_ent,
-                                       ctx->d_bin_cnt, p->hc_min_radius, p->hc_max_radius, ctx->d_rl_items, ctx->d_rl_cnt, ebx, eby, nunits);
-                }
-                I2S_SEG(10);
-                if (r30)
-                    hipLaunchKernelGGL((k_vote_lists<30>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
-                                       ctx->d_rl_items, ctx->d_rl_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list,
-                                       cent_count(ctx), ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
-                else
-                    hipLaunchKernelGGL((k_vote_lists<0>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
-                                       ctx->d_rl_items, ctx->d_rl_cnt, p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list,
-                                       cent_count(ctx), ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
-            }
+            // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
+            if (p->hc_max_radius - p->hc_min_radius + 1 == 30)
+                hipLaunchKernelGGL((k_vote_centres<30>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
+                                   p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                                   ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
+            else
+                hipLaunchKernelGGL((k_vote_centres<0>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
+                                   p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
+                                   ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
         }
-        I2S_SEG(11);
+        I2S_SEG(10);
         hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                            ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
                            ctx->d_est_keys, est_count(ctx));
-        I2S_SEG(12);
+        I2S_SEG(11);
         if (g.est_cap <= EST_UNIT)
             hipLaunchKernelGGL((k_circles_final<EST_UNIT, VCIRC_UNIT, true>), dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys,
                                est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
@@ -573,7 +544,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                                0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc,
                                vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));
-        I2S_SEG(13);
+        I2S_SEG(12);
 
         hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, ctx->d_desc, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res,
                            ctx->d_tl_cnt, ctx->d_tl_idx);
@@ -582,11 +553,11 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
                            plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, ex, ey, ctx->d_tl_cnt, ctx->d_tl_idx);
         hipLaunchKernelGGL(k_line_peaks, dim3(nb), dim3(LP_THREADS), 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
-        I2S_SEG(14);
+        I2S_SEG(13);
 
         hipLaunchKernelGGL(k_grid, dim3(nb), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, gp, 1, ctx->d_res, ctx->d_boards);
         I2S_HIP(hipEventRecord(ctx->ev[4], st));
-        I2S_SEG(15);
+        I2S_SEG(14);
 
         I2S_HIP(hipMemcpyAsync(ctx->h_boards, ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToHost, st));
         if (ctx->d_sink && dense)

@@ -49,7 +49,6 @@ struct Geo {
     int bw, bins;         // edge bins per row / per plane (32x32-pixel cells)
     int tw, tiles;        // 64x32 Canny tiles per row / per plane (hysteresis work flags)
     int cent_cap, est_cap, vcirc_cap;   // HoughCircles list capacities per (image, variant), see CENT_UNIT
-    int vtx, vtiles;      // accumulator tiles (126 x 126 cells) per row / per plane: the ray lists of k_ray_lists
     long long slot;       // pitch * hmax
 };
 

@@ -317,7 +317,7 @@ int  i2s_allgather_boards(i2s_ctx* ctx, i2s_comm* comm, const i2s_board* d_board
 /* Per-kernel timing (bench.py's roofline objects): with profiling on, a detect call records one HIP event on the
  * context's stream in front of every kernel group; i2s_last_kernel_timing returns the milliseconds each of the
  * I2S_NSEG groups took, summed over the passes of the last detect call; i2s_kernel_timing_name(i) names group i. */
-#define I2S_NSEG 15
+#define I2S_NSEG 14
 int  i2s_set_profiling(i2s_ctx* ctx, int on);
 int  i2s_last_kernel_timing(const i2s_ctx* ctx, float ms[I2S_NSEG]);
 const char* i2s_kernel_timing_name(int i);
