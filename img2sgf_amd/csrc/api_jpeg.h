@@ -220,8 +220,21 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
         // a progressive file: its leading first passes (Ah = 0)
         size_t nd = f.scans.size();
         if (f.progressive) {
+            // The device decodes these scans CONCURRENTLY, so they must write disjoint coefficients: a repeated DC first pass or
+            // overlapping AC bands -- streams libjpeg accepts with a warning and decodes in file order, last writer wins -- end the
+            // device's share at the first scan that touches a coefficient an earlier one owns.  (A run that carries past
+            // its band is caught in the write pass itself: JPG_REDO.)
+            unsigned long long owned[3] = {0ull, 0ull, 0ull};
             nd = 0;
-            while (nd < f.scans.size() && f.scans[nd].ah == 0) nd++;
+            while (nd < f.scans.size() && f.scans[nd].ah == 0) {
+                const JpegScan& sc = f.scans[nd];
+                const unsigned long long band = (sc.se >= 63 ? ~0ull : ((1ull << (sc.se + 1)) - 1ull)) & ~((1ull << sc.ss) - 1ull);
+                bool clash = false;
+                for (int k = 0; k < sc.ns; k++) clash |= (owned[sc.ci[k]] & band) != 0ull;
+                if (clash) break;
+                for (int k = 0; k < sc.ns; k++) owned[sc.ci[k]] |= band;
+                nd++;
+            }
             ok = nd > 0;
         }
         dev_scans[i] = (int)nd;
@@ -349,7 +362,7 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     }
     ctx->je_rounds = (int)round;
     hipLaunchKernelGGL(k_je_scan, dim3(cdiv((int)segs.size(), 4)), dim3(256), 0, st, d_segs, (int)segs.size(), d_acc, d_base, ctx->d_jstatus);
-    hipLaunchKernelGGL(k_je_write, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_tabs, d_blob, d_E, d_base);
+    hipLaunchKernelGGL(k_je_write, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_tabs, d_blob, d_E, d_base, ctx->d_jstatus);
     I2S_HIP(hipGetLastError());
     return I2S_OK;
 }
@@ -389,9 +402,13 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
         I2S_HIP(hipMemsetAsync(ctx->d_jpg, 0, ncoef, ctx->stream));
     }
     // progressive files the device has started: their coefficient arrays come to the host, which runs the remaining passes
-    std::vector<int> prog;
-    for (int i : par) if (files[i].progressive && (size_t)dev_scans[i] < files[i].scans.size()) prog.push_back(i);
-    if (!prog.empty()) {
+    // (every progressive file's verdict is looked at here: JPG_REDO sends the file to the serial decoder)
+    std::vector<int> prog, prog_all;
+    for (int i : par) if (files[i].progressive) {
+        prog_all.push_back(i);
+        if ((size_t)dev_scans[i] < files[i].scans.size()) prog.push_back(i);
+    }
+    if (!prog_all.empty()) {
         need_coef();
         if (coef_rc) return coef_rc;
         const int16_t* d0 = reinterpret_cast<const int16_t*>(ctx->d_jpg);
@@ -405,8 +422,18 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
         const double t0 = now_ms();
         I2S_HIP(hipStreamSynchronize(ctx->stream));
         ctx->jpeg_ms[2] += (float)(now_ms() - t0);
-        for (int i : prog)
-            if (ctx->h_jstatus[i] != JPG_OK) return jpeg_bad(ctx, order[i]);
+        bool redo = false;
+        for (int i : prog_all) {
+            if (ctx->h_jstatus[i] == JPG_REDO) {
+                // scans of this file wrote outside their bands: the whole file again, serially, in file order (jpeg_host_decode
+                // starts from zeroed arrays and the upload replaces what the device left)
+                late.push_back(i);
+                prog.erase(std::remove(prog.begin(), prog.end(), i), prog.end());
+                I2S_HIP(hipMemsetAsync(ctx->d_jstatus + i, 0, sizeof(int), ctx->stream));
+                redo = true;
+            } else if (ctx->h_jstatus[i] != JPG_OK) return jpeg_bad(ctx, order[i]);
+        }
+        (void)redo;
         const int pb = jpeg_host_finish(ctx, prog, files, order, dev_scans, coef);
         if (pb >= 0) return jpeg_bad(ctx, pb);
         rc = jpeg_host_upload(ctx, prog, files, coef);

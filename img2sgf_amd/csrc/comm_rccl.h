@@ -39,10 +39,8 @@ static RcclApi& rccl_state()
     return api;
 }
 static RcclApi* rccl_api() { RcclApi& a = rccl_state(); return a.handle ? &a : nullptr; }
-static const char* rccl_open_error() { return rccl_state().err; }
-
 // why rccl_api() returned null
-static const char* rccl_open_error();
+static const char* rccl_open_error() { return rccl_state().err; }
 
 static void rccl_open(RcclApi& api)
 {

@@ -101,6 +101,7 @@ struct i2s_ctx {
     i2s_board* d_sink = nullptr;    // i2s_set_board_sink: device array that also receives image i's record at [i]
     int* d_dbg_acc = nullptr;
     int debug = 0;
+    bool hy_no_tail = false;        // a grid barrier of k_hysteresis_tail timed out once (a shared GPU): plain launches only from then on
     int hyst_k[2] = {1, 1};         // plain hysteresis launches per phase in front of the persistent tail: what the last call needed
     int last_nb = 0;
     HoughTrig last_trig{};
@@ -259,6 +260,7 @@ extern "C" int i2s_create(i2s_ctx** out, int device_id, int max_batch, int max_w
         return I2S_E_INVALID;
     i2s_ctx* ctx = new i2s_ctx();
     ctx->device = device_id; ctx->max_batch = max_batch; ctx->max_w = max_w; ctx->max_h = max_h;
+    ctx->hy_no_tail = getenv("I2S_HYST_NO_TAIL") != nullptr;      // tests: the path a context takes after a grid-barrier timeout
     const int rc = create_impl(ctx);
     if (rc != I2S_OK) {
         if (rc == I2S_E_HIP) fprintf(stderr, "i2s_create: %s\n", ctx->err);
@@ -376,8 +378,11 @@ static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
     for (int pass = 0; pass < k; pass++)
         hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, pass,
                            worklist(ctx, phase), ctx->d_chg, queue_half, ctx->d_hmark, stamp_base);
-    hipLaunchKernelGGL(k_hysteresis_tail, dim3(HY_TAIL_BLOCKS), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, k,
-                       HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, queue_half, ctx->d_hmark, stamp_base, counter, info);
+    // the persistent tail runs whatever passes are still needed; after a barrier timeout (hy_no_tail) it is launched as ONE workgroup with
+    // no pass budget, i.e. only to report which of the k plain launches reached the fixed point (-1: none, the host redoes with more)
+    hipLaunchKernelGGL(k_hysteresis_tail, dim3(ctx->hy_no_tail ? 1 : HY_TAIL_BLOCKS), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges,
+                       flags, k, ctx->hy_no_tail ? k : HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, queue_half, ctx->d_hmark, stamp_base,
+                       counter, info);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return I2S_OK;
 }
@@ -571,6 +576,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             const int used = ctx->h_flags[ph];                              // passes the phase needed, -1: budget or barrier timeout
             if (used < 0) {
                 converged = false;
+                if (used == -2) ctx->hy_no_tail = true;                     // no second second-long timeout on this context
                 if (ctx->hyst_k[ph] >= HYST_MAX_PASSES) {
                     snprintf(ctx->err, sizeof(ctx->err), "Canny hysteresis did not converge in %d passes", HYST_MAX_PASSES);
                     return I2S_E_HIP;

@@ -79,17 +79,19 @@ __device__ __forceinline__ unsigned bytes_from_sign(unsigned t) { return __built
 // ---- grid-wide barrier of a small persistent grid (k_hysteresis_tail) ----------------------------------------------------------
 // HY_TAIL_BLOCKS workgroups of 256 threads -- one per CU, an eighth of what the chip keeps resident, so every workgroup of the grid
 // is running whatever else shares the GPU.  One monotonic counter in global memory; barrier number n is passed when it reaches
-// (n + 1) * gridDim.x.  Per MI355X_MICROARCH.md (inter-workgroup visibility): lane 0 releases at agent scope BEFORE it arrives (its
-// workgroup's stores, behind the __syncthreads, become visible in L2 / memory), polls with relaxed agent-scope loads, acquires at agent
-// scope AFTER (the CU's vector L1 is invalidated), and the inline s_waitcnt keeps the compiler from dropping the wait behind the
-// release.  Every spin is bounded: on a timeout the caller gives up and the host falls back to plain launches.
+// (n + 1) * gridDim.x.  Per MI355X_MICROARCH.md (inter-workgroup visibility): EVERY wavefront releases at agent scope before the
+// workgroup barrier in front of the arrival (its own map stores become visible in L2 / memory -- round 3 left that to lane 0 and the
+// barrier's cumulativity), lane 0 arrives and polls with relaxed agent-scope loads, and every wavefront acquires at agent
+// scope behind the second barrier (its CU's vector L1 is invalidated for ITS later loads); the inline s_waitcnt keeps the compiler
+// from dropping the wait behind the release.  Every spin is bounded: on a timeout the caller gives up and the host falls back to
+// plain launches -- for the rest of the context's life (i2s_ctx::hy_no_tail).
 constexpr int HY_TAIL_BLOCKS = 256;
 __device__ __forceinline__ bool grid_barrier(int* counter, int& target, int* s_ok)
 {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         target += (int)gridDim.x;
         __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
@@ -97,10 +99,10 @@ __device__ __forceinline__ bool grid_barrier(int* counter, int& target, int* s_o
             __builtin_amdgcn_s_sleep(8);
             if (spins > (1l << 22)) { ok = 0; break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *s_ok = ok;
     }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return *s_ok != 0;
 }
 // a value another workgroup wrote before the last grid barrier

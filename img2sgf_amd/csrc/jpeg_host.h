@@ -66,7 +66,8 @@ struct JpegFile {
     std::vector<JpegScan> scans;
 };
 
-enum { JPG_OK = 0, JPG_BAD = 1, JPG_UNSUPPORTED = 2 };
+enum { JPG_OK = 0, JPG_BAD = 1, JPG_UNSUPPORTED = 2,
+       JPG_REDO = 3 };   // device verdict only: decode this file with the serial decoder instead (jpeg_entropy_pass)
 
 static const uint8_t JPG_ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,

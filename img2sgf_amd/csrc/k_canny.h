@@ -294,11 +294,8 @@ __global__ __launch_bounds__(256) void k_hysteresis_tail(const ImgDesc* __restri
         if (!ok) break;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int used = -1;
-        if (ok && pass < max_pass) {
-            used = pass;                                                   // flags[pass - 1] == 0
-            for (int q = 0; q < pass; q++) if (load_agent(&flags[q]) == 0) { used = q + 1; break; }
-        }
+        int used = ok ? -1 : -2;                                           // -1: the budget is spent, -2: a grid barrier timed out
+        if (ok) for (int q = 0; q < pass; q++) if (load_agent(&flags[q]) == 0) { used = q + 1; break; }
         info[0] = used;
     }
 }

@@ -854,7 +854,11 @@ __global__ __launch_bounds__(256, M_WAVES) void k_median57(const ImgDesc* __rest
         if (x0 < w && y0 < h) {
             need = flags == nullptr;
             if (flags) {
-                // bands (256 x MB_R pixels) this tile's OUTPUT pixels lie in: at most 2 x 3 of them
+                // bands (256 x MB_R pixels) this tile's OUTPUT pixels lie in: at most 2 x 3 of them.  Three things make k_blur's speculation
+                // exact: the flag array is indexed with the CONTEXT's band grid (g.wmax / g.hmax never change after i2s_create,
+                // whatever the sizes of a pass's images), every tile whose output touches a flagged band is recomputed here, and the host
+                // clears the flags at the start of every pass (run_pass) -- test_blur_flags_across_passes_of_different_sizes
+                static_assert(MT_H <= 2 * MB_R && MT_W <= 256, "a tile's outputs lie in at most 2 x 3 bands");
                 const int bx0 = x0 / 256, bx1 = imin(x0 + MT_W - 1, w - 1) / 256, by0 = y0 / MB_R, by1 = imin(y0 + MT_H - 1, h - 1) / MB_R;
                 const int nbx = mb_bands_x(g.wmax), nby = mb_bands_y(g.hmax);
                 int any = 0;

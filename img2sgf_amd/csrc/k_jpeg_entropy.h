@@ -136,7 +136,8 @@ __device__ __forceinline__ int je_symbol(const JpegHuff& h, uint32_t v, int& len
 // scan, quota = first ordinal beyond the segment, pred = the DC predictors); otherwise blocks and DC differences are only counted.
 template <bool WRITE>
 __device__ __forceinline__ unsigned long long je_decode(const JeShared& sh, const uint32_t* slot, uint32_t bit0, uint32_t end,
-                                                        uint32_t L, unsigned long long state, JeAcc& acc, uint32_t q, uint32_t quota)
+                                                        uint32_t L, unsigned long long state, JeAcc& acc, uint32_t q, uint32_t quota,
+                                                        int* redo = nullptr)
 {
     if (state == JE_DEAD) return JE_DEAD;
     const JeScan& sc = sh.sc;
@@ -198,7 +199,13 @@ __device__ __forceinline__ unsigned long long je_decode(const JeShared& sh, cons
         if (dc) {
             acc.dc[0] += k == 0 ? val : 0; acc.dc[1] += k == 1 ? val : 0; acc.dc[2] += k == 2 ? val : 0;
             if (WRITE) blk[0] = (int16_t)((k == 0 ? acc.dc[0] : (k == 1 ? acc.dc[1] : acc.dc[2])) * (1 << al));
-        } else if (WRITE && !eob && s && zi < 64) blk[sh.zz[zi]] = (int16_t)(val * (1 << al));
+        } else if (WRITE && !eob && s && zi < 64) {
+            blk[sh.zz[zi]] = (int16_t)(val * (1 << al));
+            // A run that carries past the scan's band (libjpeg stores the coefficient all the same, jdphuff.c decode_mcu_AC_first) lands
+            // in a band another scan of this pass may be writing: whose value stays would depend on the scheduling.  Such a
+            // (non-conforming) file goes to the serial decoder, which applies the scans in file order.
+            if (zi > zend && redo) atomicCAS(redo, (int)JPG_OK, (int)JPG_REDO);
+        }
         if (done) {
             z = z0;
             acc.cnt += (int)run;
@@ -298,19 +305,20 @@ __global__ __launch_bounds__(256) void k_je_scan(const JeSeg* __restrict__ segs,
 // grid / block as k_je_sync: every subsequence once more, from its exact entry state, coefficients stored.
 __global__ __launch_bounds__(JE_BLOCK) void k_je_write(const JeScan* __restrict__ scans, const JeSeg* __restrict__ segs, const int* __restrict__ blk_scan,
                                                         const JpegHuff* __restrict__ tabs, const uint32_t* __restrict__ blob,
-                                                        const unsigned long long* __restrict__ E, const JeAcc* __restrict__ base)
+                                                        const unsigned long long* __restrict__ E, const JeAcc* __restrict__ base, int* __restrict__ status)
 {
     __shared__ JeShared sh;
     const JeScan& sc = scans[blk_scan[blockIdx.x]];
     const uint32_t g = blockIdx.x * JE_BLOCK + threadIdx.x;
     const bool active = g - sc.sub0 < sc.nsub;
     uint32_t j = 0, off_dw = 0, L = 0, blk0 = 0, nblk = 0;
+    int file = 0;
     if (active) {
         const JeSeg& sg = segs[je_find_seg(segs, sc, g)];
         j = g - sg.sub0;
         L = sg.nbytes * 8;
         off_dw = sg.off / 4 + j * (JE_SUB_BYTES / 4);
-        blk0 = sg.blk0; nblk = sg.nblk;
+        blk0 = sg.blk0; nblk = sg.nblk; file = sg.file;
     }
     je_stage(sh, sc, tabs, blob, off_dw, active);
     if (!active) return;
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_write(const JeScan* __restrict_
     if ((uint32_t)acc.cnt >= nblk) return;
     const bool last = (j + 1) * JE_SUB_BITS >= L;
     const uint32_t end = last ? L : (j + 1) * JE_SUB_BITS;
-    je_decode<true>(sh, sh.slot + threadIdx.x * JE_SLOT, j * JE_SUB_BITS, end, L, entry, acc, blk0 + (uint32_t)acc.cnt, blk0 + nblk);
+    je_decode<true>(sh, sh.slot + threadIdx.x * JE_SLOT, j * JE_SUB_BITS, end, L, entry, acc, blk0 + (uint32_t)acc.cnt, blk0 + nblk, status + file);
 }
 
 }  // namespace i2s

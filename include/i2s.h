@@ -297,6 +297,9 @@ int  i2s_last_timing(const i2s_ctx* ctx, float ms[5]);
  *                communicator's buffer); d_boards need only hold the n_local <= records_per_rank records that are valid on
  *                this rank (records from elsewhere are copied into the shard first; the tail of the shard is zeroed); h_all,
  *                if not NULL, receives a host copy of all [world][records_per_rank] records.
+ *                NOTE: a d_boards that is not the shard therefore OVERWRITES the shard -- including records a board sink
+ *                (i2s_set_board_sink(shard + k)) has delivered there: use one way of filling the shard per gather, not both.
+ *                The gather is the in-place form (sendbuff == recvbuff + rank * count) exactly when d_all is NULL or i2s_comm_all().
  *                Synchronous on return.  Rank r's records are those of images shard_range(total, r, world).
  * librccl is opened with dlopen on first use; I2S_E_NO_DEVICE if it is missing.  i2s_comm_create is collective even in failure:
  * a rank whose local allocation fails still takes part in ncclCommInitRank and reports afterwards.

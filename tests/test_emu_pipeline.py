@@ -235,6 +235,19 @@ def test_jpeg_decode_matches_pillow(lib):
         for k, r in enumerate(refs):
             np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d, entropy mode %d" % (k, mode))
         assert (det.jpeg_last_rounds() > 0) == (mode == 1)         # the parallel decoder ran (and needed more than the first round)
+    # first passes that are not disjoint (repeated bands, runs past the band's end: tests/jpeg_transcode.py::to_progressive): the
+    # device's share ends at the clash / the file goes to the serial decoder; Pillow's pixels on every path
+    buf = io.BytesIO()
+    Image.fromarray(col[:40, :56]).save(buf, "JPEG", quality=80, subsampling=2)
+    clean = [(0, 1, 5, 1), (1, 1, 63, 1), (2, 1, 63, 1), (0, 6, 63, 1)]
+    odd = [jpeg_transcode.to_progressive(buf.getvalue(), clean),
+           jpeg_transcode.to_progressive(buf.getvalue(), [(0, 1, 5, 1), (0, 3, 9, -1), (1, 1, 63, 1), (2, 1, 63, 1), (0, 6, 63, 1)]),
+           jpeg_transcode.to_progressive(buf.getvalue(), clean, overrun=(0, 3))]
+    odd_refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in odd]
+    for mode in (0, 1, 2):
+        det.detect_jpeg(odd, Params(jpeg_entropy_device=mode), full=False)
+        for k, r in enumerate(odd_refs):
+            np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="non-conforming progressive file %d, entropy mode %d" % (k, mode))
     # a pass beyond the iteration's limit is handed to the serial decoder
     det.jpeg_set_max_rounds(1)
     det.detect_jpeg(blobs, Params(), full=False)

@@ -316,3 +316,46 @@ def test_board_sink_with_more_files_than_one_pass(schedule):
         np.testing.assert_array_equal(got[k], want, err_msg="sink[%d] (%s)" % (k, n))
     assert (got[len(names)] == 0xEE).all()                                        # nothing past the batch was touched
     det.close()
+
+
+def _nonconforming_progressive_files():
+    """Progressive files whose first passes are NOT disjoint (tests/jpeg_transcode.py::to_progressive): (a) all first passes, clean --
+    the control; (b) an AC band coded twice, with different values; (c) the DC scan's band repeated by an AC scan that starts at 0
+    is not legal, so: two overlapping luminance bands AND a repeated chroma band; (d) code words whose run carries past the band's
+    end into a band a later scan writes.  libjpeg accepts all of them (with warnings) and applies the scans in file order."""
+    import jpeg_transcode as T
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:72, 0:88]
+    img = np.stack([(xx * 3 + yy * 2) % 256, (xx * yy) % 256, 255 - (xx + yy) % 256], -1).astype(np.uint8)
+    img[20:40, 30:60] = rng.integers(0, 256, (20, 30, 3))
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", quality=85, subsampling=2)
+    base = buf.getvalue()
+    clean = [(0, 1, 5, 1), (1, 1, 63, 1), (2, 1, 63, 1), (0, 6, 63, 1)]
+    return [T.to_progressive(base, clean),
+            T.to_progressive(base, [(0, 1, 5, 1), (0, 3, 9, -1), (1, 1, 63, 1), (2, 1, 63, 1), (0, 6, 63, 1)]),
+            T.to_progressive(base, [(0, 1, 9, 1), (1, 1, 63, 1), (0, 6, 63, -1), (2, 1, 63, 1), (1, 1, 20, -1)]),
+            T.to_progressive(base, clean, overrun=(0, 3)),
+            T.to_progressive(base, [(0, 1, 5, 1), (0, 6, 63, 1), (1, 1, 30, 1), (1, 31, 63, 1), (2, 1, 63, 1)], overrun=(2, -2))]
+
+
+def test_overlapping_first_passes_decode_in_file_order_on_every_path():
+    """the device decodes the leading first passes of a progressive file concurrently, which is only the file's meaning
+    while they write disjoint coefficients.  Scans that repeat a band end the device's share (jpeg_parallel), a run that carries past
+    its band sends the file to the serial decoder (JPG_REDO): all three entropy paths must give Pillow's pixels, every time."""
+    blobs = _nonconforming_progressive_files()
+    refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
+    assert any((refs[k] != refs[0]).any() for k in (1, 2, 3, 4))           # the defects do change the picture
+    det = Detector(0, len(blobs), 96, 80)
+    for mode in (0, 1, 2, 1, 1):
+        det.detect_jpeg(blobs, Params(jpeg_entropy_device=mode), full=False)
+        for k, r in enumerate(refs):
+            np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d, entropy mode %d" % (k, mode))
+    # many copies in one pass: more workgroups in flight, more chances for a scheduling-dependent result
+    many = [blobs[k % len(blobs)] for k in range(40)]
+    det2 = Detector(0, len(many), 96, 80)
+    for _ in range(3):
+        det2.detect_jpeg(many, Params(jpeg_entropy_device=1), full=False)
+        for k in range(len(many)):
+            np.testing.assert_array_equal(det2.fetch_source(k, 3), refs[k % len(blobs)], err_msg="copy %d" % k)
+    det.close(); det2.close()

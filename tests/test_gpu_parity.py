@@ -462,3 +462,55 @@ def test_plain_rounding_gaussian_taps_use_the_integer_kernels():
         np.testing.assert_array_equal(det.fetch_plane(0, name), cvo.gaussian_blur(img, k, k, 1))
     np.testing.assert_array_equal(det.fetch_plane(0, "median3"), cvo.median_blur(img, 3))
     det.close()
+
+
+def test_hysteresis_plain_launch_path_equals_the_persistent_tail(monkeypatch):
+    """ADVICE r3: after ONE grid-barrier timeout of k_hysteresis_tail a context stops using it (i2s_ctx::hy_no_tail: plain launches, the
+    tail kernel only reports which pass reached the fixed point).  I2S_HYST_NO_TAIL puts a fresh context on that path: several batches
+    of mixed noisy images, serpentines and diagrams must give the same Canny maps, edge images and records as the persistent tail --
+    and both must equal the oracle."""
+    rng = np.random.default_rng(12)
+    h, w = 256, 512
+    snake = np.full((h, w), 100, np.uint8)
+    for y in range(20, h - 20, 24):
+        snake[y:y + 12, 10:w - 10] = 130
+    for k, y in enumerate(range(20, h - 44, 24)):
+        x = w - 30 if k % 2 == 0 else 10
+        snake[y:y + 36, x:x + 20] = 130
+    snake[20:32, 10:14] = 255
+    batches = []
+    for r in range(4):
+        batches.append([snake if (r + k) % 3 == 0 else (synth.synth_diagram(r * 8 + k, geom=synth.GEOM_SMALL, noisy=k % 2 == 0)[0] if k % 3 == 1
+                        else rng.integers(0, 256, (int(rng.integers(40, 256)), int(rng.integers(40, 512))), dtype=np.uint8)) for k in range(8)])
+    tail = Detector(0, 8, w, h)
+    monkeypatch.setenv("I2S_HYST_NO_TAIL", "1")
+    plain = Detector(0, 8, w, h)
+    monkeypatch.delenv("I2S_HYST_NO_TAIL")
+    for r, batch in enumerate(batches):
+        da = tail.detect_batch(batch, full=False)
+        db = plain.detect_batch(batch, full=False)
+        for k in range(len(batch)):
+            assert bytes(da[k]) == bytes(db[k]), (r, k)
+            for plane in ["edges", "removed"] + [9 + m for m in range(9)]:
+                np.testing.assert_array_equal(tail.fetch_plane(k, plane), plain.fetch_plane(k, plane), err_msg="batch %d image %d plane %s" % (r, k, plane))
+    parity.run_and_compare(plain, batches[0])
+    tail.close(); plain.close()
+
+
+def test_blur_flags_across_passes_of_different_sizes():
+    """k_blur's "this band is not two-valued" flags live in a per-context array indexed with the context's band grid and are
+    cleared every pass.  One context, passes whose images differ in size: a large 0 / 255 image with stray grey pixels in its LAST band
+    row and column (flags at the far edge of the grid), then small images whose bands are all clean, then the large one again, then a
+    several-pass batch mixing both -- all six blur planes against the oracle every time."""
+    rng = np.random.default_rng(21)
+    big = np.where(rng.random((200, 600)) < 0.5, 0, 255).astype(np.uint8)
+    big[199, 599] = 128; big[193, 3] = 7; big[5, 597] = 200
+    small = np.where(rng.random((70, 90)) < 0.5, 0, 255).astype(np.uint8)
+    small_clean_then_grey = small.copy(); small_clean_then_grey[69, 89] = 100
+    noisy = rng.integers(0, 256, (130, 300), dtype=np.uint8)
+    det = Detector(0, 2, 600, 200)
+    for batch in ([big], [small], [big, small], [small, small_clean_then_grey], [noisy], [small], [big, small, noisy, small_clean_then_grey, big]):
+        # (_blur_planes_match compares the planes of the LAST device pass: batches longer than max_batch are checked pass by pass)
+        for k in range(0, len(batch), 2):
+            _blur_planes_match(det, batch[k:k + 2])
+    det.close()
