@@ -479,7 +479,18 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             // votes), the others are flagged for the bit-serial kernel
             const int bgx = cdiv(wmax, 1024), bgy = cdiv(hmax, BL_R);      // 4 wavefronts x 256 pixels, BL_R rows
             I2S_SEG(2);                                                    // (the k_median57_bin segment stays empty on this path)
-            hipLaunchKernelGGL(k_blur, dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
+            // speculative two-valued kernel (all six planes of the bands it finishes), then the general kernel on the bands it flagged.
+            // The 16-bit sums of the first stay below 65536 until the last multiply-add (which saturates) only if every tap is positive
+            bool bin_ok = true;
+            for (int k = 0; k < 3; k++) bin_ok &= t3.k[k] > 0;
+            for (int k = 0; k < 5; k++) bin_ok &= t5.k[k] > 0;
+            for (int k = 0; k < 7; k++) bin_ok &= t7.k[k] > 0;
+            if (bin_ok)
+                hipLaunchKernelGGL((k_blur<true>), dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
+                                   plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7),
+                                   plane_ptr(ctx, I2S_PLANE_MEDIAN5), plane_ptr(ctx, I2S_PLANE_MEDIAN7), bt, ctx->d_mflags, bgx, bgy);
+            else I2S_HIP(hipMemsetAsync(ctx->d_mflags, 0xff, (size_t)nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int), st));
+            hipLaunchKernelGGL((k_blur<false>), dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
                                plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7),
                                plane_ptr(ctx, I2S_PLANE_MEDIAN5), plane_ptr(ctx, I2S_PLANE_MEDIAN7), bt, ctx->d_mflags, bgx, bgy);
         } else {

@@ -19,6 +19,7 @@ __device__ __forceinline__ int imed3(int a, int b, int c) { int r; asm("v_med3_i
 //  * (float)a + (float)b of two bytes becomes an SDWA integer add + v_cvt_f32_u32 (two half-rate instructions per sum);
 //    converting every byte once with v_cvt_f32_ubyteN and adding floats (full rate) is cheaper.
 __device__ __forceinline__ float bl_vgpr(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+__device__ __forceinline__ unsigned bl_vgpr_u(unsigned x) { unsigned r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 template <int BYTE> __device__ __forceinline__ float bl_fb(unsigned v)
 {
     float r;
@@ -49,6 +50,11 @@ __device__ __forceinline__ unsigned bl_bload(BlBuf b, int row_off, unsigned off)
 #ifndef BL_STORE_AUX
 #define BL_STORE_AUX 2
 #endif
+// A lane offset beyond the descriptor's 2 GB window (BL_NO_STORE) makes the hardware drop that lane's store: lanes and whole rows are
+// switched off this way, WITHOUT a branch around the instruction -- the compiler's s_waitcnt pass counts only the memory operations
+// issued on EVERY path, so stores behind a branch do not count and its waits for the prefetched rows become waits for nearly all
+// outstanding stores as well (k_blur: vmcnt(10) instead of vmcnt(40), 3.4 instead of ~6 TB/s of plane writes)
+constexpr unsigned BL_NO_STORE = 0xffffffffu;
 __device__ __forceinline__ void bl_bstore(BlBuf b, int row_off, unsigned off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.r, (int)off, row_off, BL_STORE_AUX); }
 
 // "The prefetched registers are needed HERE": an empty statement that consumes them, so that the wait for the loads is placed
@@ -75,6 +81,23 @@ __device__ __forceinline__ unsigned alignbyte(unsigned hi, unsigned lo, unsigned
 // 0xff / 0x00 per byte from the byte's top bit: v_perm_b32 selectors 8 .. 11 replicate the sign of bytes 1, 3, 5, 7 of {hi:lo};
 // with hi = t << 8 those are bytes 1, 3 (lo) and 0, 2 (hi) of t.
 __device__ __forceinline__ unsigned bytes_from_sign(unsigned t) { return __builtin_amdgcn_perm(t << 8, t, 0x090b080au); }
+
+// Two unsigned 16-bit values per register (VOP3P): the two-valued mode of k_blur keeps pixels (x0, x0 + 2) and (x0 + 1, x0 + 3) of a
+// lane's dword in the halves of two registers.  pk_mad_u16_sat saturates each half at 65535 (the instruction's clamp bit).
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2u16 pk_v(unsigned u) { v2u16 r; __builtin_memcpy(&r, &u, 4); return r; }
+__device__ __forceinline__ unsigned pk_u(v2u16 v) { unsigned u; __builtin_memcpy(&u, &v, 4); return u; }
+__device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b) { return pk_u(pk_v(a) + pk_v(b)); }
+__device__ __forceinline__ unsigned pk_mul_u16(unsigned a, unsigned b) { return pk_u(pk_v(a) * pk_v(b)); }
+__device__ __forceinline__ unsigned pk_mad_u16(unsigned a, unsigned b, unsigned c) { return pk_u(pk_v(a) * pk_v(b) + pk_v(c)); }
+__device__ __forceinline__ unsigned pk_mad_u16_sat(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// a.lo * b.lo + a.hi * b.hi + c in 32 bits (v_dot2_u32_u16)
+__device__ __forceinline__ unsigned udot2_u16(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot2(pk_v(a), pk_v(b), c, false); }
 
 // ---- grid-wide barrier of a small persistent grid (k_hysteresis_tail) ----------------------------------------------------------
 // HY_TAIL_BLOCKS workgroups of 256 threads -- one per CU, an eighth of what the chip keeps resident, so every workgroup of the grid

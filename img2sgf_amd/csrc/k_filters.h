@@ -203,6 +203,9 @@ __device__ __forceinline__ void bl_median_pixels(unsigned L, unsigned M, unsigne
 #ifndef BL_WAVES
 #define BL_WAVES 3
 #endif
+#ifndef BL_WAVES_BIN
+#define BL_WAVES_BIN 4        // the two-valued kernel keeps its rings as 16-bit pairs: half the registers of the float rings
+#endif
 #ifndef BL_DEPTH
 #define BL_DEPTH 6        // rows of loads in flight (3: 2.18, 4: 2.04, 5 / 6: 1.93, 8: 1.91 us per diagram)
 #endif
@@ -218,7 +221,8 @@ __device__ __forceinline__ void bl_median_pixels(unsigned L, unsigned M, unsigne
 // 3x3 sorting network, and k_median57 (the bit-serial kernel, below) then computes the 5x5 / 7x7 medians of every tile that touches a
 // flagged band, overwriting whatever the speculation had written.  Either way every output pixel is exact.
 // flags[(b * bands_y + band row) * bands_x + column group] != 0: the band holds a pixel other than 0 / 255 (zeroed by the host)
-__global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
+template <bool BIN_KERNEL>
+__global__ __launch_bounds__(256, BIN_KERNEL ? BL_WAVES_BIN : BL_WAVES) void k_blur(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ med3,
                                                  uint8_t* __restrict__ out3, uint8_t* __restrict__ out5, uint8_t* __restrict__ out7,
                                                  uint8_t* __restrict__ med5, uint8_t* __restrict__ med7,
                                                  BlurTaps tps, int* __restrict__ band_flags, int gx, int gy)
@@ -229,6 +233,10 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
     tp.c3 = bl_vgpr(tps.c3 * S); tp.a3 = bl_vgpr(tps.a3 * S);
     tp.c5 = bl_vgpr(tps.c5 * S); tp.a5 = bl_vgpr(tps.a5 * S); tp.b5 = bl_vgpr(tps.b5 * S);
     tp.c7 = bl_vgpr(tps.c7 * S); tp.a7 = bl_vgpr(tps.a7 * S); tp.b7 = bl_vgpr(tps.b7 * S); tp.d7 = bl_vgpr(tps.d7 * S);
+    // the two-valued kernel: integer taps, one per 16-bit half (in vector registers for the same reason)
+    auto pkt = [](float t) { const unsigned u = (unsigned)t; return bl_vgpr_u(u | (u << 16)); };
+    const unsigned k_c3 = pkt(tps.c3), k_a3 = pkt(tps.a3), k_c5 = pkt(tps.c5), k_a5 = pkt(tps.a5), k_b5 = pkt(tps.b5);
+    const unsigned k_c7 = pkt(tps.c7), k_a7 = pkt(tps.a7), k_b7 = pkt(tps.b7), k_d7 = pkt(tps.d7);
     // block = 4 wavefronts = 4 consecutive 256-pixel column groups of one band of BL_R rows
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z;
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
     auto walk = [&](auto bin_tag) -> bool {
         constexpr bool BIN = decltype(bin_tag)::value;
         float H3[7][4], H5[7][4], H7[7][4];        // horizontal results of the last 7 input rows, slot = row index mod 7
+        unsigned P3[7][2], P5[7][2], P7[7][2];     // BIN: the same as 16-bit pairs ([0]: pixels x0, x0 + 2; [1]: x0 + 1, x0 + 3), values <= 256
         int F1[6], F2[6];                           // general mode, 3x3 median ring: pixels x0-1 .. x0+4 of the two previous rows
         unsigned RB[7];                             // BIN: packed row sums of the last 7 rows (BORDER_REPLICATE rows), slot = row index mod 7
         unsigned S3 = 0, S5 = 0, S7 = 0;            // BIN: vertical running sums (rows t-4 .. t-2, t-5 .. t-1, t-6 .. t)
@@ -320,6 +329,7 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             RB[i] = 0;
+            P3[i][0] = P3[i][1] = P5[i][0] = P5[i][1] = P7[i][0] = P7[i][1] = 0u;
 #pragma unroll
             for (int q = 0; q < 4; q++) { H3[i][q] = 0.f; H5[i][q] = 0.f; H7[i][q] = 0.f; }
         }
@@ -336,60 +346,94 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
         }
         // BL_DEPTH rows in flight: vmcnt counts loads and stores together and in order, so the wait for a row's pixels is also a
         // wait for every store issued before that load -- the deeper the queue, the more rows of stores may still be on their way
+        // The rows in flight sit in a RING of 7 slots, statically indexed like the result rings below (slot = row index mod 7): row t is
+        // read from slot u, the load of row t + BL_DEPTH goes to slot (u + BL_DEPTH) % 7.  Rounds 2-3 kept them in a shift queue
+        // (q[d] = q[d + 1] every row): the moves READ the newest entries, so the compiler had to wait for the load issued one row
+        // earlier -- s_waitcnt vmcnt(10) -- and with it, the counter being in order, for every store but the last row's: at most eight
+        // stores in flight per wavefront, 3.4 TB/s of plane writes where the same load / store scheme streams 6.2
+        // (tools/micro/store_bw_bench.hip; ablations in profiles/r04_b_blur_experiments.txt).
+        static_assert(BL_DEPTH >= 1 && BL_DEPTH <= 6, "the ring has 7 slots: at most 6 rows in flight beside the current one");
         BlReflect ry;
         ry.init(y0 - 3, h);
-        unsigned nM, nE;
-        {
-            const int ro = rowoff(ry.y, sp);
-            nM = bl_bload(sbuf, ro, xm);
-            nE = bl_bload(sbuf, ro, xe);
-        }
-        unsigned qM[BL_DEPTH - 1], qE[BL_DEPTH - 1];
+        unsigned qM[7], qE[7];
 #pragma unroll
-        for (int d = 0; d < BL_DEPTH - 1; d++) {
-            ry.step();
-            const int ro = rowoff(ry.y, sp);
+        for (int d = 0; d < 7; d++) { qM[d] = 0; qE[d] = 0; }
+#pragma unroll
+        for (int d = 0; d < BL_DEPTH; d++) {
+            if (d > 0) ry.step();
+            const int ro = __builtin_amdgcn_readfirstlane(rowoff(ry.y, sp));      // uniform: without this every load sits in a waterfall loop
             qM[d] = bl_bload(sbuf, ro, xm);
             qE[d] = bl_bload(sbuf, ro, xe);
+            // The compiler's s_waitcnt for a ring slot must hold on the FIRST trip through the row loop too, where the slot was loaded
+            // here: it counts the memory operations issued after that load on the shortest path.  The prologue therefore issues what a
+            // row of the loop issues -- its stores, rejected by the range check -- so that the count is the loop's (BL_DEPTH - 1 rows of
+            // loads AND stores may stay in flight) and not the prologue's loads alone (vmcnt(10): hardly more than one row of stores)
+#pragma unroll
+            for (int k = 0; k < (BIN ? 6 : 5); k++) bl_bstore(o_3, 0, BL_NO_STORE, 0u);
         }
+        // (the first row is tested before the loop -- its load has to have arrived for the first trip anyway -- so that a band of a noisy
+        // image is given up at once and not after seven rows)
+        unsigned odd_acc = BIN ? ((((qM[0] >> 1) ^ qM[0]) & vm) | (((qE[0] >> 1) ^ qE[0]) & ve)) : 0u;
         for (int t0 = 0; t0 < t_end; t0 += 7) {
+            // (the test for a byte that is neither 0 nor 255 leaves the row loop only here: an exit inside the unrolled rows makes the
+            // compiler's wait counts fall back to the prologue's, see above; what the rows since the last test stored is overwritten)
+            if (BIN && __any(odd_acc != 0u)) return false;
 #pragma unroll
             for (int u = 0; u < 7; u++) {
                 const int t = t0 + u;
                 const int yi = y0 - 3 + t;
-                const unsigned M = nM, E = nE;
-                nM = qM[0]; nE = qE[0];
-#pragma unroll
-                for (int d = 0; d + 1 < BL_DEPTH - 1; d++) { qM[d] = qM[d + 1]; qE[d] = qE[d + 1]; }
+                const unsigned M = qM[u], E = qE[u];
+                unsigned& nM = qM[(u + 1) % 7];
+                unsigned& nE = qE[(u + 1) % 7];
                 {
                     ry.step();
-                    const int ro = rowoff(ry.y, sp);
-                    qM[BL_DEPTH - 2] = bl_bload(sbuf, ro, xm);
-                    qE[BL_DEPTH - 2] = bl_bload(sbuf, ro, xe);
+                    const int ro = __builtin_amdgcn_readfirstlane(rowoff(ry.y, sp));
+                    qM[(u + BL_DEPTH) % 7] = bl_bload(sbuf, ro, xm);
+                    qE[(u + BL_DEPTH) % 7] = bl_bload(sbuf, ro, xe);
                 }
-                if (BIN) {
-                    const unsigned odd = (((M >> 1) ^ M) & vm) | (((E >> 1) ^ E) & ve);
-                    if (__any(odd != 0u)) return false;
-                }
+                if (BIN) odd_acc |= (((M >> 1) ^ M) & vm) | (((E >> 1) ^ E) & ve);      // tested once per 7 rows, below
                 const unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E);
                 unsigned gl = L, gm = M, gr = R;
                 if (fix) {
+                    BL_KEEP_BRANCH();
                     gl = __builtin_amdgcn_perm(M, L, gA[0]);
                     gm = __builtin_amdgcn_perm(M, L, gA[1]);
                     gr = __builtin_amdgcn_perm(R, __builtin_amdgcn_perm(M, L, gA[2]), gB2);
                 }
-                float f[10];                                              // pixels x0 - 3 .. x0 + 6
-                f[0] = bl_f(gl, 1); f[1] = bl_f(gl, 2); f[2] = bl_f(gl, 3);
-                f[3] = bl_f(gm, 0); f[4] = bl_f(gm, 1); f[5] = bl_f(gm, 2); f[6] = bl_f(gm, 3);
-                f[7] = bl_f(gr, 0); f[8] = bl_f(gr, 1); f[9] = bl_f(gr, 2);
-                // horizontal pass of the three Gaussians into ring slot u
+                // the row's 0 / 1 bytes and their shifted copies (BIN): byte q of A<k> / B<k> = pixel x0 + q - k / x0 + q + k
+                unsigned bA1 = 0, bA2 = 0, bA3 = 0, bB1 = 0, bB2 = 0, bB3 = 0, bC = 0;
+                if (BIN) {
+                    // horizontal pass on the 0 / 1 BYTES (four pixels per add), weights as 16-bit pairs (two pixels per multiply-add):
+                    // a pixel is 255 b, so the Gaussian is (255 v + 32768) >> 16 with v = sum of tap products over the window's ones --
+                    // h = sum_k w_k b <= 256 here, v <= 65536 in the vertical pass
+                    const unsigned fl = gl & 0x01010101u, fm = gm & 0x01010101u, fr = gr & 0x01010101u;
+                    bA1 = alignbyte(fm, fl, 3); bB1 = alignbyte(fr, fm, 1);
+                    bA2 = alignbyte(fm, fl, 2); bB2 = alignbyte(fr, fm, 2);
+                    bA3 = alignbyte(fm, fl, 1); bB3 = alignbyte(fr, fm, 3);
+                    bC = fm;
+                    const unsigned s1 = bA1 + bB1, s2 = bA2 + bB2, s3 = bA3 + bB3;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float c = f[q + 3];
-                    const float s1 = f[q + 2] + f[q + 4], s2 = f[q + 1] + f[q + 5], s3 = f[q] + f[q + 6];
-                    H3[u][q] = __builtin_fmaf(tp.a3, s1, tp.c3 * c);
-                    H5[u][q] = __builtin_fmaf(tp.b5, s2, __builtin_fmaf(tp.a5, s1, tp.c5 * c));
-                    H7[u][q] = __builtin_fmaf(tp.d7, s3, __builtin_fmaf(tp.b7, s2, __builtin_fmaf(tp.a7, s1, tp.c7 * c)));
+                    for (int hf = 0; hf < 2; hf++) {
+                        const unsigned ce = (bC >> (8 * hf)) & 0x00ff00ffu, e1 = (s1 >> (8 * hf)) & 0x00ff00ffu;
+                        const unsigned e2 = (s2 >> (8 * hf)) & 0x00ff00ffu, e3 = (s3 >> (8 * hf)) & 0x00ff00ffu;
+                        P3[u][hf] = pk_mad_u16(k_a3, e1, pk_mul_u16(k_c3, ce));
+                        P5[u][hf] = pk_mad_u16(k_b5, e2, pk_mad_u16(k_a5, e1, pk_mul_u16(k_c5, ce)));
+                        P7[u][hf] = pk_mad_u16(k_d7, e3, pk_mad_u16(k_b7, e2, pk_mad_u16(k_a7, e1, pk_mul_u16(k_c7, ce))));
+                    }
+                } else {
+                    float f[10];                                              // pixels x0 - 3 .. x0 + 6
+                    f[0] = bl_f(gl, 1); f[1] = bl_f(gl, 2); f[2] = bl_f(gl, 3);
+                    f[3] = bl_f(gm, 0); f[4] = bl_f(gm, 1); f[5] = bl_f(gm, 2); f[6] = bl_f(gm, 3);
+                    f[7] = bl_f(gr, 0); f[8] = bl_f(gr, 1); f[9] = bl_f(gr, 2);
+                    // horizontal pass of the three Gaussians into ring slot u
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float c = f[q + 3];
+                        const float s1 = f[q + 2] + f[q + 4], s2 = f[q + 1] + f[q + 5], s3 = f[q] + f[q + 6];
+                        H3[u][q] = __builtin_fmaf(tp.a3, s1, tp.c3 * c);
+                        H5[u][q] = __builtin_fmaf(tp.b5, s2, __builtin_fmaf(tp.a5, s1, tp.c5 * c));
+                        H7[u][q] = __builtin_fmaf(tp.d7, s3, __builtin_fmaf(tp.b7, s2, __builtin_fmaf(tp.a7, s1, tp.c7 * c)));
+                    }
                 }
                 const int yo = yi - 3;
                 const bool st_g = t >= 6 && yo < h;
@@ -401,7 +445,15 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
                     unsigned p;
                     if (yi < 0) p = p_first;
                     else if (yi >= h) p = p_last;
-                    else { p = bin_row(L, M, R); p_last = p; }
+                    else {
+                        // (away from the image's left / right edge the medians' REPLICATE triple is the Gaussians' REFLECT_101 triple)
+                        if (fix) p = bin_row(L, M, R);
+                        else {
+                            const unsigned h3 = bA1 + bC + bB1, h5 = h3 + bA2 + bB2, h7 = h5 + bA3 + bB3;
+                            p = h3 | (h5 << 2) | (h7 << 5);
+                        }
+                        p_last = p;
+                    }
                     const unsigned old = RB[u];                               // row t - 7
                     S7 += ((p >> 5) & 0x07070707u) - ((old >> 5) & 0x07070707u);
                     S5 += ((RB[(u + 6) % 7] >> 2) & 0x07070707u) - ((RB[(u + 1) % 7] >> 2) & 0x07070707u);
@@ -423,7 +475,29 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
                 }
                 // vertical pass: output row yo = yi - 3 from ring slots t-6 .. t (centre t-3)
                 unsigned o3w = 0, o5w = 0, o7w = 0;
-                if (st_g) {
+                if (st_g && BIN) {
+                    constexpr int NS = 7;
+                    const int c = (u + 4) % NS, p1 = (u + 5) % NS, m1 = (u + 3) % NS, p2 = (u + 6) % NS, m2 = (u + 2) % NS, p3 = u, m3 = (u + 1) % NS;
+                    // v per pixel in 16 bits: every partial sum lacks a positive term of the all-ones window's 65536, only the last
+                    // multiply-add can reach it -- that one saturates at 65535, and (255 * 65535 + 32768) >> 16 is 255 as well
+                    unsigned v3[2], v5[2], v7[2];
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        v3[hf] = pk_mad_u16_sat(k_c3, P3[c][hf], pk_mul_u16(k_a3, pk_add_u16(P3[p1][hf], P3[m1][hf])));
+                        v5[hf] = pk_mad_u16_sat(k_c5, P5[c][hf], pk_mad_u16(k_a5, pk_add_u16(P5[p1][hf], P5[m1][hf]),
+                                                                             pk_mul_u16(k_b5, pk_add_u16(P5[p2][hf], P5[m2][hf]))));
+                        v7[hf] = pk_mad_u16_sat(k_c7, P7[c][hf], pk_mad_u16(k_a7, pk_add_u16(P7[p1][hf], P7[m1][hf]),
+                                                pk_mad_u16(k_b7, pk_add_u16(P7[p2][hf], P7[m2][hf]), pk_mul_u16(k_d7, pk_add_u16(P7[p3][hf], P7[m3][hf])))));
+                    }
+                    // (255 v + 32768) >> 16: byte 2 of a 32-bit dot product per pixel, gathered with two byte permutes
+                    auto finish = [](const unsigned (&v)[2]) {
+                        const unsigned q0 = udot2_u16(v[0], 0x000000ffu, 32768u), q2 = udot2_u16(v[0], 0x00ff0000u, 32768u);
+                        const unsigned q1 = udot2_u16(v[1], 0x000000ffu, 32768u), q3 = udot2_u16(v[1], 0x00ff0000u, 32768u);
+                        return __builtin_amdgcn_perm(q1, q0, 0x0c0c0602u) | __builtin_amdgcn_perm(q3, q2, 0x06020c0cu);
+                    };
+                    o3w = finish(v3); o5w = finish(v5); o7w = finish(v7);
+                }
+                if (st_g && !BIN) {
                     constexpr int NS = 7;
                     const int c = (u + 4) % NS, p1 = (u + 5) % NS, m1 = (u + 3) % NS, p2 = (u + 6) % NS, m2 = (u + 2) % NS, p3 = u, m3 = (u + 1) % NS;
                     float r3[4], r5[4], r7[4];
@@ -444,32 +518,35 @@ __global__ __launch_bounds__(256, BL_WAVES) void k_blur(const ImgDesc* __restric
                 BL_SCHED_FENCE();
                 BL_CONSUME(nM, nE);
                 BL_SCHED_FENCE();
-                if (active) {
-                    if (!BIN) {
-                        if (st_m) bl_bstore(o_m, rowoff(yi - 1, g.pitch), xm, om);
-                        if (st_m2) bl_bstore(o_m, rowoff(yi, g.pitch), xm, om2);
-                    }
-                    if (st_g) {
-                        const int off = rowoff(yo, g.pitch);
-                        bl_bstore(o_3, off, xm, o3w);
-                        bl_bstore(o_5, off, xm, o5w);
-                        bl_bstore(o_7, off, xm, o7w);
-                        if (BIN) {
-                            bl_bstore(o_m, off, xm, om);
-                            bl_bstore(o_m5, off, xm, om5);
-                            bl_bstore(o_m7, off, xm, om7);
-                        }
+                // every store is issued on every path (see BL_NO_STORE): lanes beyond the image and rows that complete nothing get an
+                // offset the buffer's range check rejects
+                {
+                    const int off = rowoff(yo, g.pitch);
+                    const unsigned xg = (active && st_g) ? xm : BL_NO_STORE;
+                    bl_bstore(o_3, off, xg, o3w);
+                    bl_bstore(o_5, off, xg, o5w);
+                    bl_bstore(o_7, off, xg, o7w);
+                    if (BIN) {
+                        bl_bstore(o_m, off, xg, om);
+                        bl_bstore(o_m5, off, xg, om5);
+                        bl_bstore(o_m7, off, xg, om7);
+                    } else {
+                        bl_bstore(o_m, rowoff(yi - 1, g.pitch), (active && st_m) ? xm : BL_NO_STORE, om);
+                        bl_bstore(o_m, rowoff(yi, g.pitch), (active && st_m2) ? xm : BL_NO_STORE, om2);
                     }
                 }
             }
         }
-        return true;
+        return !(BIN && __any(odd_acc != 0u));
     };
-    if (band_flags != nullptr) {
-        if (walk(std::true_type{})) return;
-        if (lane == 0) band_flags[((size_t)b * mb_bands_y(g.hmax) + tl.ty) * mb_bands_x(g.wmax) + cgp] = 1;
+    int* flag = band_flags ? band_flags + ((size_t)b * mb_bands_y(g.hmax) + tl.ty) * mb_bands_x(g.wmax) + cgp : nullptr;
+    if (BIN_KERNEL) {
+        // the speculative walk; a band that turns out not to be two-valued is flagged and left to the general kernel behind this one
+        if (!walk(std::true_type{}) && lane == 0) *flag = 1;
+    } else {
+        if (flag != nullptr && *flag == 0) return;                    // the two-valued kernel has written all six planes of this band
+        walk(std::false_type{});
     }
-    walk(std::false_type{});
 }
 
 // ---- K4: exact medians, BORDER_REPLICATE (cv.medianBlur, img2sgf.py:174).

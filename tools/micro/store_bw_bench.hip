@@ -2,6 +2,7 @@
 // a wavefront walks down R rows of a 256-pixel column group; per row it reads 256 B of one plane and writes 256 B (dword per lane) to
 // each of P output planes.  Variants: stores plain / nt; dword per lane vs dwordx4 per lane (a wavefront then covers 1024 B of a row).
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -137,5 +138,34 @@ int main()
     RUN_A(2, 2, 25, 64); RUN_A(2, 2, 50, 64); RUN_A(2, 2, 100, 64); RUN_A(2, 2, 200, 64); RUN_A(2, 4, 50, 64); RUN_A(2, 4, 100, 64);
     RUN_A(4, 4, 100, 64); RUN_A(4, 4, 200, 64);
     RUN_S(4, 2, true, true, 64); RUN_S(4, 4, true, true, 64); RUN_S(4, 4, false, false, 64); RUN_S(6, 4, true, true, 64);
+    // Round 4: what ONE launch costs in a pipeline, where it is neither repeated nor preceded by itself: single launches of the
+    // 6-plane scheme, timed one by one -- (a) back to back, (b) each after the GPU sat idle for 3 ms, (c) idle and into a region
+    // of memory that was not written for three launches.  (The table above averages five back-to-back launches after a warm-up.)
+    {
+        unsigned* big;
+        CK(hipMalloc(&big, plane * NIMG * PMAX * 4));
+        hipEvent_t ev[9];
+        for (int i = 0; i < 9; i++) CK(hipEventCreate(&ev[i]));
+        auto launch = [&](unsigned* d) { hipLaunchKernelGGL((k_rows_scheme<6, 4, true, true>), dim3(W / 1024, H / 64, NIMG), dim3(256), 0, 0, (const uint8_t*)src, (uint8_t*)d, W, 64, H, plane); };
+        for (int mode = 0; mode < 3; mode++) {
+            CK(hipDeviceSynchronize());
+            usleep(5000);
+            float ms[8];
+            if (mode == 0) {
+                for (int i = 0; i < 8; i++) { CK(hipEventRecord(ev[i])); launch(big); }
+                CK(hipEventRecord(ev[8])); CK(hipEventSynchronize(ev[8]));
+                for (int i = 0; i < 8; i++) CK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+            } else {
+                for (int i = 0; i < 8; i++) {
+                    usleep(3000);
+                    CK(hipEventRecord(ev[0])); launch(big + (mode == 2 ? (size_t)(i % 4) * plane * NIMG * PMAX / 4 : 0)); CK(hipEventRecord(ev[1]));
+                    CK(hipEventSynchronize(ev[1])); CK(hipEventElapsedTime(&ms[i], ev[0], ev[1]));
+                }
+            }
+            printf("%-52s", mode == 0 ? "single launches, back to back (ms):" : (mode == 1 ? "single launches, 3 ms idle before each:" : "... idle and a region not written for 3 launches:"));
+            for (int i = 0; i < 8; i++) printf(" %.3f", ms[i]);
+            printf("\n");
+        }
+    }
     return 0;
 }
