@@ -114,7 +114,7 @@ struct i2s_ctx {
 
 // segments of i2s_last_kernel_timing, in launch order
 static const char* const kSegName[I2S_NSEG] = {
-    "k_grey", "k_median57_bin", "k_blur", "k_median57", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)",
+    "k_grey", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)", "k_median57_bin", "k_blur", "k_median57",
     "k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
     "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
 #define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
@@ -473,12 +473,31 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
         I2S_SEG(0);
         if (need_grey) hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
+        // Order of the two independent halves of the blur+Canny stage (round 4): the main Canny FIRST.  It is bound by its arithmetic and
+        // does not care where the grey source comes from; k_blur is bound by its six plane stores, and those stream ~15 % faster when
+        // the source it reads at the same time is already in the Infinity Cache than when HBM has to turn around between reads and
+        // writes (profiles/r04_b_blur_experiments.txt: 1.92 -> 1.69 us per diagram with the source read by a kernel in front of it).
+        // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
+        // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
+        const bool fused0 = has_c1 && p->canny_lo == hc_lo;
         I2S_SEG(1);
+        const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
+        if (fused0)
+            hipLaunchKernelGGL((k_sobel_nms_rows<2>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
+                               p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
+        else if (has_c1)
+            hipLaunchKernelGGL((k_sobel_nms_rows<1>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
+                               p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
+        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
+        I2S_SEG(2);
+        rc = run_hysteresis(ctx, 0, fx * fy * nb);
+        if (rc) return rc;
+        I2S_SEG(3);
         if (float_blur) {
             // the three Gaussians and the 3x3 median; bands of pure 0 / 255 pixels get their 5x5 / 7x7 medians here as well (majority
             // votes), the others are flagged for the bit-serial kernel
             const int bgx = cdiv(wmax, 1024), bgy = cdiv(hmax, BL_R);      // 4 wavefronts x 256 pixels, BL_R rows
-            I2S_SEG(2);                                                    // (the k_median57_bin segment stays empty on this path)
+            I2S_SEG(4);                                                    // (the k_median57_bin segment stays empty on this path)
             // speculative two-valued kernel (all six planes of the bands it finishes), then the general kernel on the bands it flagged.
             // The 16-bit sums of the first stay below 65536 until the last multiply-add (which saturates) only if every tap is positive
             bool bin_ok = true;
@@ -498,29 +517,14 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             const int mbx = cdiv(wmax, 1024), mby = cdiv(hmax, MB_R);    // 4 wavefronts x 256 pixels, MB_R rows
             hipLaunchKernelGGL(k_median57_bin, dim3((unsigned)mbx * mby * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                                plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mbx, mby);
-            I2S_SEG(2);
+            I2S_SEG(4);
             hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
             hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GAUSS3),
                                plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
         }
-        I2S_SEG(3);
+        I2S_SEG(5);
         hipLaunchKernelGGL(k_median57, dim3((unsigned)cdiv(mx * my * nb, M_TPB)), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                            plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mx, my, mx * my * nb);
-        // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
-        // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
-        const bool fused0 = has_c1 && p->canny_lo == hc_lo;
-        I2S_SEG(4);
-        const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
-        if (fused0)
-            hipLaunchKernelGGL((k_sobel_nms_rows<2>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
-                               p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
-        else if (has_c1)
-            hipLaunchKernelGGL((k_sobel_nms_rows<1>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
-                               p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
-        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
-        I2S_SEG(5);
-        rc = run_hysteresis(ctx, 0, fx * fy * nb);
-        if (rc) return rc;
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
         I2S_SEG(6);
         const int v_first = fused0 ? 1 : 0;
