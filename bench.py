@@ -45,6 +45,37 @@ CANNY7_BYTES = 7 * 2 * N_PIX   # HoughCircles' internal Canny of the 7 planes th
 NOISE_SIGMA = 6.0              # SURVEY 8(d) config 2, variant "noisy": N(0, 6^2) added to the same diagrams, clipped
 
 
+def fixtures_roofline(device, copies=16):
+    """The blur+Canny stage on the reference's OWN inputs: the 18 fixtures (tests/golden/test_images: data, committed) after the
+    reference's default contrast / brightness step (Pillow on the host, img2sgf.py:136-150), `copies` times, one device pass, one
+    stream, HIP events in front of every kernel.  Real scans are 88-97 % pure black / white PIXELS, but anti-aliased strokes touch
+    nearly every 256 x 64 band, so the two-valued speculation of k_blur rarely holds: this, not the synthetic diagrams' figure,
+    is what the stage does on a user's files.  Bytes: 14 per processed pixel (SURVEY 8d's unfused accounting, C = 1)."""
+    from img2sgf_amd import preprocess
+    from img2sgf_amd.pipeline import Detector, Params
+    d = os.path.join(ROOT, "tests", "golden", "test_images")
+    names = sorted(n for n in os.listdir(d) if n.endswith(".jpg")) if os.path.isdir(d) else []
+    if not names:
+        return None
+    imgs = [np.ascontiguousarray(preprocess.enhance(preprocess.load_image(os.path.join(d, n)), 70, 50)) for n in names] * copies
+    det = Detector(device, len(imgs), max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    det.set_profiling(True)
+    det.detect_batch(imgs, Params(), full=False)
+    det.detect_batch(imgs, Params(), full=False)
+    seg = det.last_kernel_timing()
+    flagged, total = det.blur_band_stats()
+    det.close()
+    pixels = sum(i.shape[0] * i.shape[1] for i in imgs)
+    stage_s = sum(seg.get(k, 0.0) for k in BLUR_CANNY_SEGS) * 1e-3
+    ach = 14.0 * pixels / stage_s / 1e9
+    return {"bound": "hbm", "kernel": "blur+Canny stage on the reference's 18 fixtures x %d (default contrast / brightness), ragged sizes, one pass" % copies,
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes": 14 * pixels, "pixels": pixels, "stage_us": stage_s * 1e6,
+            "bands_not_two_valued": flagged, "bands": total, "bands_not_two_valued_frac": flagged / max(total, 1),
+            "kernel_us": {k: seg[k] * 1e3 for k in BLUR_CANNY_SEGS if k in seg},
+            "whole_path_images_per_s_single_stream": len(imgs) / (sum(seg.values()) * 1e-3)}
+
+
 def cpu_baseline(per_worker):
     """tools/cpu_baseline.py in its own interpreter (its workers fork; no HIP runtime in their parent): the reference's
     ten cv2 calls + glue when cv2 is importable (kind "cv2": B1 = 1 process with OpenCV's own thread pool, B2 = one
@@ -106,6 +137,7 @@ def main():
     ap.add_argument("--roofline-images", type=int, default=256)
     ap.add_argument("--cpu-per-worker", type=int, default=8, help="diagrams per CPU worker process in the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-fixtures", action="store_true", help="skip the roofline_fixtures leg (the stage on the reference's 18 scans)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -258,6 +290,8 @@ def main():
             "kernel_us_per_image": {k: v * 1e3 / nr for k, v in seg.items()},
             "single_stream_stage_ms": timing,
         }
+        if not args.no_fixtures:
+            out["roofline_fixtures"] = fixtures_roofline(local)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_per_worker)
         print(json.dumps(out))

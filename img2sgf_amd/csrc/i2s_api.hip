@@ -945,6 +945,23 @@ extern "C" int i2s_set_profiling(i2s_ctx* ctx, int on)
     return I2S_OK;
 }
 
+extern "C" int i2s_blur_band_stats(i2s_ctx* ctx, int* flagged, int* total)
+{
+    if (!ctx || !flagged || !total || ctx->last_nb <= 0) return I2S_E_INVALID;
+    I2S_HIP(hipSetDevice(ctx->device));
+    const int nbx = mb_bands_x(ctx->geo.wmax), nby = mb_bands_y(ctx->geo.hmax);
+    std::vector<int> f((size_t)ctx->last_nb * nbx * nby);
+    I2S_HIP(hipMemcpy(f.data(), ctx->d_mflags, f.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int nf = 0, nt = 0;
+    for (int b = 0; b < ctx->last_nb; b++) {
+        const int bx = mb_bands_x(ctx->h_desc[b].w), by = mb_bands_y(ctx->h_desc[b].h);
+        for (int y = 0; y < by; y++)
+            for (int x = 0; x < bx; x++) { nt++; nf += f[((size_t)b * nby + y) * nbx + x] != 0; }
+    }
+    *flagged = nf; *total = nt;
+    return I2S_OK;
+}
+
 extern "C" int i2s_last_kernel_timing(const i2s_ctx* ctx, float ms[I2S_NSEG])
 {
     if (!ctx || !ms || !ctx->prof) return I2S_E_INVALID;

@@ -428,6 +428,12 @@ class Detector:
         """Per-kernel HIP events on this context's stream (include/i2s.h: i2s_set_profiling)."""
         self._check(self.lib.dll.i2s_set_profiling(self._ctx, 1 if on else 0))
 
+    def blur_band_stats(self):
+        """(flagged, total): bands of the last device pass that were NOT two-valued (went through the general blur / median kernels)."""
+        f, t = C.c_int(), C.c_int()
+        self._check(self.lib.dll.i2s_blur_band_stats(self._ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def last_kernel_timing(self):
         """{kernel group: ms} of the last detect call, in launch order (profiling must be on)."""
         ms = (C.c_float * _lib.NSEG)()

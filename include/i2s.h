@@ -324,6 +324,9 @@ int  i2s_allgather_boards(i2s_ctx* ctx, i2s_comm* comm, const i2s_board* d_board
 int  i2s_set_profiling(i2s_ctx* ctx, int on);
 int  i2s_last_kernel_timing(const i2s_ctx* ctx, float ms[I2S_NSEG]);
 const char* i2s_kernel_timing_name(int i);
+/* The blur bank's two-valued speculation (k_blur) on the last device pass: of the `total` 256 x 64-pixel bands of its images, `flagged`
+ * held a pixel that is neither 0 nor 255 and went through the general kernels (Gaussians + sorting network + bit-sliced medians). */
+int  i2s_blur_band_stats(i2s_ctx* ctx, int* flagged, int* total);
 
 /* Debug/test hooks (not part of the drop-in surface): Hough-circle accumulator of variant v
  * ((h)x(w) int32, cell layout = pixel layout) and line accumulators. Enabled by

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_roofline.md: the bench line's roofline fractions recomputed from TRACKED files only -- the per-dispatch kernel traces of
+the clean and the noisy workload (tools/rocpd_sequence.py output of two separate rocprofv3 --kernel-trace runs of tools/kernel_times.py)
+and profiles/traffic.json (PMC passes).  Usage: roofline_md.py TAG [bench.json]   (reads profiles/TAG_{clean,noisy}_dispatches.csv)"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N14 = 14 * 1024 * 1024
+STAGE = ("k_grey", "k_blur", "k_median3", "k_gauss357", "k_median57_bin", "k_median57")
+
+
+def base(name):
+    return name.split("<")[0]
+
+
+def passes(path):
+    """[{group: us}] per device pass of the trace (a pass ends with k_grid)."""
+    rows = [r for r in csv.DictReader(open(path)) if base(r["kernel"]).startswith("k_")]
+    out, cur, hc_seen = [], None, False
+    for r in rows:
+        k, full, d = base(r["kernel"]), r["kernel"], float(r["duration_us"])
+        if cur is None:
+            cur, hc_seen = {}, False
+        if k == "k_sobel_nms_rows" and "<0>" in full:
+            hc_seen = True
+            g = "k_sobel_nms_rows(HoughCircles x7)"
+        elif k in ("k_sobel_nms_rows", "k_sobel_nms_src"):
+            g = "k_sobel_nms(main Canny)"
+        elif k in ("k_hysteresis", "k_hysteresis_tail"):
+            g = "k_hysteresis(HoughCircles)" if hc_seen else "k_hysteresis(main Canny)"
+        else:
+            g = k
+        cur[g] = cur.get(g, 0.0) + d
+        if k == "k_grid":
+            out.append(cur)
+            cur = None
+    return out
+
+
+def table(ps, images):
+    keys = []
+    for p in ps:
+        for k in p:
+            if k not in keys:
+                keys.append(k)
+    avg = {k: sum(p.get(k, 0.0) for p in ps) / len(ps) for k in keys}
+    lines = ["| kernel group | us per pass (mean of %d passes) | us per diagram |" % len(ps), "|---|---|---|"]
+    for k in keys:
+        lines.append("| `%s` | %.1f | %.3f |" % (k, avg[k], avg[k] / images))
+    lines.append("| **sum** | %.1f | **%.2f** |" % (sum(avg.values()), sum(avg.values()) / images))
+    return avg, "\n".join(lines)
+
+
+def stage_us(avg):
+    return sum(v for k, v in avg.items() if k in STAGE or k in ("k_sobel_nms(main Canny)", "k_hysteresis(main Canny)"))
+
+
+def main():
+    tag = sys.argv[1]
+    images = 256
+    prof = os.path.join(ROOT, "profiles")
+    clean = passes(os.path.join(prof, tag + "_clean_dispatches.csv"))
+    noisy = passes(os.path.join(prof, tag + "_noisy_dispatches.csv"))
+    ac, tc = table(clean, images)
+    an, tn = table(noisy, images)
+    sc, sn = stage_us(ac) / images, stage_us(an) / images
+    c7 = (ac["k_sobel_nms_rows(HoughCircles x7)"] + ac.get("k_hysteresis(HoughCircles)", 0.0)) / images
+    traffic = json.load(open(os.path.join(prof, "traffic.json")))
+    c7b = traffic.get("canny7_hbm_bytes_per_image") or 0
+    md = [
+        "# %s: the roofline fractions of the bench line, recomputed from tracked files" % tag, "",
+        "Inputs: `profiles/%s_clean_dispatches.csv` and `profiles/%s_noisy_dispatches.csv` -- every kernel dispatch, in launch order, of two SEPARATE" % (tag, tag),
+        "`rocprofv3 --kernel-trace` runs of `python tools/kernel_times.py --images 256 --pass-size 256 --reps 3` (clean diagrams) and `... --noisy`",
+        "(sigma = 6 on the same diagrams); one stream, 256 diagrams per device pass, nothing else on the GPU.  `tools/profile_round.sh %s` makes them," % tag,
+        "`tools/roofline_md.py %s` writes this file.  N = 1024 x 1024; the blur+Canny stage's algorithmic bytes are 14 N = 14 680 064 per diagram" % tag,
+        "(SURVEY 8d, unfused accounting); peak 8.0 TB/s.", "",
+        "## clean diagrams (BASELINE configs[2] workload)", "", tc, "",
+        "blur+Canny stage = `k_grey` + `k_sobel_nms(main Canny)` + `k_hysteresis(main Canny)` + `k_blur` (both instances) + `k_median57`: **%.3f us per diagram**" % sc,
+        "-> 14 N / %.3f us = %.2f TB/s = **roofline.frac %.3f**." % (sc, N14 / sc / 1e6, N14 / sc / 1e6 / 8.0), "",
+        "HoughCircles' seven internal Cannys = `k_sobel_nms_rows<0>` + its hysteresis launches: %.3f us per diagram -> %.2f TB/s = **roofline_canny7.frac %.3f**."
+        % (c7, N14 / c7 / 1e6, N14 / c7 / 1e6 / 8.0), "",
+        "`k_vote_centres`: %.2f us per diagram; with the bench line's `votes_per_image` V, roofline_k5.frac = V / %.2f us / 8.29e12 votes/s."
+        % (ac["k_vote_centres"] / images, ac["k_vote_centres"] / images), "",
+        "## noisy diagrams", "", tn, "",
+        "blur+Canny stage: **%.3f us per diagram** -> %.2f TB/s = **roofline_noisy.frac %.3f**." % (sn, N14 / sn / 1e6, N14 / sn / 1e6 / 8.0), "",
+        "## HBM traffic (PMC)", "",
+        "`profiles/traffic.json` (kernels hash `%s`): FETCH_SIZE and WRITE_SIZE of one pass of %d clean diagrams, separate `--pmc` passes, FETCH_SIZE x 2 per"
+        % (traffic.get("kernels_sha"), traffic.get("images", 0)),
+        "MI355X_MICROARCH.md: blur+Canny stage **%.2f MB per diagram = %.2f x 14 N**; the seven Cannys %.2f MB = %.2f x their 14 N."
+        % (traffic["blur_canny_hbm_bytes_per_image"] / 1e6, traffic["ratio_to_algorithmic"], c7b / 1e6, c7b / N14),
+        "Infinity-Cache caveat: a pass of 256 diagrams reads 256 MiB of sources -- the size of the Infinity Cache -- and writes 4.6 GB of planes.  Since",
+        "round 4 the main Canny runs first and k_blur re-reads the sources it left in that cache (deliberately: profiles/r04_b_blur_experiments.txt),",
+        "so part of k_blur's source reads never reach HBM; the plane traffic (12 of the 14 N) is far beyond any cache.", ""]
+    if len(sys.argv) > 2 and os.path.exists(sys.argv[2]):
+        b = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+        md += ["## against the bench line (`%s`)" % os.path.relpath(os.path.abspath(sys.argv[2]), ROOT), "",
+               "| | bench line (HIP events on the stream, one pass of 256) | from the traces above | ratio |", "|---|---|---|---|"]
+        for name, bv, tv in (("roofline.frac", b["roofline"]["frac"], N14 / sc / 1e6 / 8.0),
+                             ("roofline_noisy.frac", b["roofline_noisy"]["frac"], N14 / sn / 1e6 / 8.0),
+                             ("roofline_canny7.frac", b["roofline_canny7"]["frac"], N14 / c7 / 1e6 / 8.0),
+                             ("k_vote_centres us per diagram", b["roofline_k5"]["us_per_image"], ac["k_vote_centres"] / images)):
+            md.append("| %s | %.4f | %.4f | %.3f |" % (name, bv, tv, tv / bv))
+        md.append("")
+    out = os.path.join(prof, tag + "_roofline.md")
+    open(out, "w").write("\n".join(md))
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main()
