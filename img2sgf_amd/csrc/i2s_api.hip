@@ -2,6 +2,7 @@
 // One context = one GPU = one HIP stream; a detect call streams the batch through the device in passes of
 // `max_batch` images with a single synchronisation per pass.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -44,6 +45,8 @@ struct JpegCoefHost {
     size_t size() const { return n; }
     int reserve(struct i2s_ctx* ctx, size_t count);
 };
+
+struct ProfPair { int seg; hipEvent_t start, stop; };
 
 struct i2s_ctx {
     int device = 0, max_batch = 0, max_w = 0, max_h = 0;
@@ -107,7 +110,8 @@ struct i2s_ctx {
     HoughTrig last_trig{};
     float timing[5] = {0, 0, 0, 0, 0};
     int prof = 0;                   // i2s_set_profiling: per-kernel HIP events on the stream
-    hipEvent_t pev[I2S_NSEG + 1] = {};
+    std::vector<ProfPair> prof_pairs;   // event pairs of the launches of the current pass (profiling)
+    size_t prof_used = 0;
     float seg_ms[I2S_NSEG] = {};
     char err[256] = {0};
 };
@@ -117,7 +121,18 @@ static const char* const kSegName[I2S_NSEG] = {
     "k_grey", "k_sobel_nms(main Canny)", "k_hysteresis(main Canny)", "k_median57_bin", "k_blur", "k_median57",
     "k_sobel_nms_rows(HoughCircles x7)", "k_hysteresis(HoughCircles)", "k_edge_bins", "k_vote_centres", "k_radius",
     "k_circles_final", "k_concat_circles+k_erase_lines+k_line_peaks", "k_grid"};
-#define I2S_SEG(i) do { if (ctx->prof) I2S_HIP(hipEventRecord(ctx->pev[i], st)); } while (0)
+// Kernel launches of the detection pass.  With profiling on (i2s_set_profiling) a launch goes through hipExtLaunchKernelGGL, which
+// stamps the kernel's own start and stop into a pair of events: i2s_last_kernel_timing then reports kernel DURATIONS per group, the
+// quantity a rocprofv3 kernel trace reports -- rounds 1-3 recorded one event in front of every group, which also counted the
+// dispatch gaps and the markers themselves (7 % on the blur+Canny stage: profiles/r04_roofline.md).
+static bool prof_pair(i2s_ctx* ctx, int seg, hipEvent_t* s, hipEvent_t* e);
+#define I2S_LAUNCH(seg, kernel, grid, block, ...)                                                                     \
+    do {                                                                                                              \
+        hipEvent_t ps_, pe_;                                                                                          \
+        if (ctx->prof && prof_pair(ctx, seg, &ps_, &pe_))                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ps_, pe_, 0, __VA_ARGS__);                      \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, __VA_ARGS__);                                    \
+    } while (0)
 
 #define I2S_HIP(call)                                                                                   \
     do {                                                                                                \
@@ -183,7 +198,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob, ctx->h_coef.p};
     for (void* q : host) if (q) (void)hipHostFree(q);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    for (int i = 0; i <= I2S_NSEG; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
+    for (ProfPair& pp : ctx->prof_pairs) { (void)hipEventDestroy(pp.start); (void)hipEventDestroy(pp.stop); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -356,6 +371,20 @@ static GridParams grid_params(const i2s_params* p)
 
 static inline int* worklist(i2s_ctx* ctx, int phase) { return ctx->d_weak + (size_t)phase * ((size_t)ctx->max_batch * NMAP * ctx->geo.tiles + 1); }
 
+static bool prof_pair(i2s_ctx* ctx, int seg, hipEvent_t* s, hipEvent_t* e)
+{
+    if (ctx->prof_used == ctx->prof_pairs.size()) {
+        ProfPair pp{seg, nullptr, nullptr};
+        if (hipEventCreate(&pp.start) != hipSuccess) return false;
+        if (hipEventCreate(&pp.stop) != hipSuccess) { (void)hipEventDestroy(pp.start); return false; }
+        ctx->prof_pairs.push_back(pp);
+    }
+    ProfPair& pp = ctx->prof_pairs[ctx->prof_used++];
+    pp.seg = seg;
+    *s = pp.start; *e = pp.stop;
+    return true;
+}
+
 // One phase of hysteresis (0: the main Canny's map, 1: HoughCircles' maps): hyst_k[phase] plain launches -- as many passes as the
 // previous call needed -- and ONE persistent launch behind them that runs whatever is still necessary with grid-wide barriers and
 // reports the number of passes the phase took (k_canny.h).  On diagrams that is 1 + 1 launches per phase.
@@ -375,12 +404,13 @@ static int run_hysteresis(i2s_ctx* ctx, int phase, int max_tiles)
     }
     const int stamp_base = ctx->hy_stamp;
     ctx->hy_stamp += HYST_MAX_PASSES + 2;
+    const int seg = phase == 0 ? 2 : 7;            // i2s_last_kernel_timing: "k_hysteresis(main Canny)" / "k_hysteresis(HoughCircles)"
     for (int pass = 0; pass < k; pass++)
-        hipLaunchKernelGGL(k_hysteresis, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges, flags, pass,
+        I2S_LAUNCH(seg, k_hysteresis, dim3(nblocks), dim3(256), ctx->d_desc, ctx->geo, maps, edges, flags, pass,
                            worklist(ctx, phase), ctx->d_chg, queue_half, ctx->d_hmark, stamp_base);
     // the persistent tail runs whatever passes are still needed; after a barrier timeout (hy_no_tail) it is launched as ONE workgroup with
     // no pass budget, i.e. only to report which of the k plain launches reached the fixed point (-1: none, the host redoes with more)
-    hipLaunchKernelGGL(k_hysteresis_tail, dim3(ctx->hy_no_tail ? 1 : HY_TAIL_BLOCKS), dim3(256), 0, ctx->stream, ctx->d_desc, ctx->geo, maps, edges,
+    I2S_LAUNCH(seg, k_hysteresis_tail, dim3(ctx->hy_no_tail ? 1 : HY_TAIL_BLOCKS), dim3(256), ctx->d_desc, ctx->geo, maps, edges,
                        flags, k, ctx->hy_no_tail ? k : HYST_MAX_PASSES, worklist(ctx, phase), ctx->d_chg, queue_half, ctx->d_hmark, stamp_base,
                        counter, info);
     I2S_HIP(hipMemcpyAsync(&ctx->h_flags[phase], info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -451,6 +481,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     bt.c7 = (float)t7.k[3]; bt.a7 = (float)t7.k[2]; bt.b7 = (float)t7.k[1]; bt.d7 = (float)t7.k[0];
 
     for (;;) {
+        ctx->prof_used = 0;                          // (a redone pass measures itself again)
         I2S_HIP(hipMemcpyAsync(ctx->d_desc, ctx->h_desc, nb * sizeof(ImgDesc), hipMemcpyHostToDevice, st));
         I2S_HIP(hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx), st));
         I2S_HIP(hipMemsetAsync(ctx->d_flags, 0, (2 * HYST_MAX_PASSES + 4) * sizeof(int), st));
@@ -471,8 +502,8 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         const dim3 g_row((unsigned)rx * ry * nb), g_f((unsigned)fx * fy * nb), g_m((unsigned)mx * my * nb);
 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
-        I2S_SEG(0);
-        if (need_grey) hipLaunchKernelGGL(k_grey, g_row, b64x4, 0, st, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
+        // -- kernel group 0 of i2s_last_kernel_timing
+        if (need_grey) I2S_LAUNCH(0, k_grey, g_row, b64x4, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
         // Order of the two independent halves of the blur+Canny stage (round 4): the main Canny FIRST.  It is bound by its arithmetic and
         // does not care where the grey source comes from; k_blur is bound by its six plane stores, and those stream ~15 % faster when
         // the source it reads at the same time is already in the Infinity Cache than when HBM has to turn around between reads and
@@ -480,24 +511,24 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
         // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
         const bool fused0 = has_c1 && p->canny_lo == hc_lo;
-        I2S_SEG(1);
+        // -- kernel group 1 of i2s_last_kernel_timing
         const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
         if (fused0)
-            hipLaunchKernelGGL((k_sobel_nms_rows<2>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
+            I2S_LAUNCH(1, (k_sobel_nms_rows<2>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
                                p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
         else if (has_c1)
-            hipLaunchKernelGGL((k_sobel_nms_rows<1>), dim3((unsigned)cgx * cgy * nb), b256, 0, st, ctx->d_desc, g, grey, map0, edges, 0,
+            I2S_LAUNCH(1, (k_sobel_nms_rows<1>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0,
                                p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
-        if (has_c3) hipLaunchKernelGGL((k_sobel_nms_src<3>), g_f, b256, 0, st, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
-        I2S_SEG(2);
+        if (has_c3) I2S_LAUNCH(1, (k_sobel_nms_src<3>), g_f, b256, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
+        // -- kernel group 2 of i2s_last_kernel_timing
         rc = run_hysteresis(ctx, 0, fx * fy * nb);
         if (rc) return rc;
-        I2S_SEG(3);
+        // -- kernel group 3 of i2s_last_kernel_timing
         if (float_blur) {
             // the three Gaussians and the 3x3 median; bands of pure 0 / 255 pixels get their 5x5 / 7x7 medians here as well (majority
             // votes), the others are flagged for the bit-serial kernel
             const int bgx = cdiv(wmax, 1024), bgy = cdiv(hmax, BL_R);      // 4 wavefronts x 256 pixels, BL_R rows
-            I2S_SEG(4);                                                    // (the k_median57_bin segment stays empty on this path)
+            // -- kernel group 4 of i2s_last_kernel_timing  // (the k_median57_bin segment stays empty on this path)
             // speculative two-valued kernel (all six planes of the bands it finishes), then the general kernel on the bands it flagged.
             // The 16-bit sums of the first stay below 65536 until the last multiply-add (which saturates) only if every tap is positive
             bool bin_ok = true;
@@ -505,79 +536,78 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             for (int k = 0; k < 5; k++) bin_ok &= t5.k[k] > 0;
             for (int k = 0; k < 7; k++) bin_ok &= t7.k[k] > 0;
             if (bin_ok)
-                hipLaunchKernelGGL((k_blur<true>), dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
+                I2S_LAUNCH(4, (k_blur<true>), dim3((unsigned)bgx * bgy * nb), b256, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
                                    plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7),
                                    plane_ptr(ctx, I2S_PLANE_MEDIAN5), plane_ptr(ctx, I2S_PLANE_MEDIAN7), bt, ctx->d_mflags, bgx, bgy);
             else I2S_HIP(hipMemsetAsync(ctx->d_mflags, 0xff, (size_t)nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int), st));
-            hipLaunchKernelGGL((k_blur<false>), dim3((unsigned)bgx * bgy * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
+            I2S_LAUNCH(4, (k_blur<false>), dim3((unsigned)bgx * bgy * nb), b256, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3),
                                plane_ptr(ctx, I2S_PLANE_GAUSS3), plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7),
                                plane_ptr(ctx, I2S_PLANE_MEDIAN5), plane_ptr(ctx, I2S_PLANE_MEDIAN7), bt, ctx->d_mflags, bgx, bgy);
         } else {
             // integer kernels (tap sets that do not sum to 256): the two-valued bands' 5x5 / 7x7 majority votes have a kernel of their own
             const int mbx = cdiv(wmax, 1024), mby = cdiv(hmax, MB_R);    // 4 wavefronts x 256 pixels, MB_R rows
-            hipLaunchKernelGGL(k_median57_bin, dim3((unsigned)mbx * mby * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+            I2S_LAUNCH(4, k_median57_bin, dim3((unsigned)mbx * mby * nb), b256, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                                plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mbx, mby);
-            I2S_SEG(4);
-            hipLaunchKernelGGL(k_median3, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
-            hipLaunchKernelGGL(k_gauss357, g_f, b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GAUSS3),
+            // -- kernel group 4 of i2s_last_kernel_timing
+            I2S_LAUNCH(4, k_median3, g_f, b256, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN3), fx, fy);
+            I2S_LAUNCH(4, k_gauss357, g_f, b256, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_GAUSS3),
                                plane_ptr(ctx, I2S_PLANE_GAUSS5), plane_ptr(ctx, I2S_PLANE_GAUSS7), t3, t5, t7, fx, fy);
         }
-        I2S_SEG(5);
-        hipLaunchKernelGGL(k_median57, dim3((unsigned)cdiv(mx * my * nb, M_TPB)), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
+        // -- kernel group 5 of i2s_last_kernel_timing
+        I2S_LAUNCH(5, k_median57, dim3((unsigned)cdiv(mx * my * nb, M_TPB)), b256, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_MEDIAN5),
                            plane_ptr(ctx, I2S_PLANE_MEDIAN7), ctx->d_mflags, mx, my, mx * my * nb);
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
-        I2S_SEG(6);
+        // -- kernel group 6 of i2s_last_kernel_timing
         const int v_first = fused0 ? 1 : 0;
-        hipLaunchKernelGGL((k_sobel_nms_rows<0>), dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, 0, st, ctx->d_desc, g, grey, map0,
+        I2S_LAUNCH(6, (k_sobel_nms_rows<0>), dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, ctx->d_desc, g, grey, map0,
                            (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
-        I2S_SEG(7);
+        // -- kernel group 7 of i2s_last_kernel_timing
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;
-        I2S_SEG(8);
-        hipLaunchKernelGGL(k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), dim3(EBT), 0, st, ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
+        // -- kernel group 8 of i2s_last_kernel_timing
+        I2S_LAUNCH(8, k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), dim3(EBT), ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
                            ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
-        I2S_SEG(9);
+        // -- kernel group 9 of i2s_last_kernel_timing
         // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
         {
             static_assert(NVAR % 2 == 0, "k_vote_centres pairs the HoughCircles inputs");
             const unsigned vgrid = (unsigned)vx * vy * nb * (NVAR / 2);
             // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled
             if (p->hc_max_radius - p->hc_min_radius + 1 == 30)
-                hipLaunchKernelGGL((k_vote_centres<30>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
+                I2S_LAUNCH(9, (k_vote_centres<30>), dim3(vgrid), dim3(VPT), ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                                    p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
                                    ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
             else
-                hipLaunchKernelGGL((k_vote_centres<0>), dim3(vgrid), dim3(VPT), 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
+                I2S_LAUNCH(9, (k_vote_centres<0>), dim3(vgrid), dim3(VPT), ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                                    p->hc_min_radius, p->hc_max_radius, p->hc_param2, ctx->d_cent_list, cent_count(ctx),
                                    ctx->debug ? ctx->d_dbg_acc : (int*)nullptr, vx, vy);
         }
-        I2S_SEG(10);
-        hipLaunchKernelGGL(k_radius, dim3(RAD_GX, nb * NVAR), b256, 0, st, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
+        // -- kernel group 10 of i2s_last_kernel_timing
+        I2S_LAUNCH(10, k_radius, dim3(RAD_GX, nb * NVAR), b256, ctx->d_desc, g, ctx->d_bin_ent, ctx->d_bin_cnt,
                            ctx->d_cent_list, cent_count(ctx), p->hc_min_radius, p->hc_max_radius, p->hc_param2,
                            ctx->d_est_keys, est_count(ctx));
-        I2S_SEG(11);
+        // -- kernel group 11 of i2s_last_kernel_timing
         if (g.est_cap <= EST_UNIT)
-            hipLaunchKernelGGL((k_circles_final<EST_UNIT, VCIRC_UNIT, true>), dim3(nb * NVAR), dim3(FIN_THREADS), 0, st, g, ctx->d_est_keys,
+            I2S_LAUNCH(11, (k_circles_final<EST_UNIT, VCIRC_UNIT, true>), dim3(nb * NVAR), dim3(FIN_THREADS), g, ctx->d_est_keys,
                                est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc, vcount(ctx), overflow(ctx));
         else
-            hipLaunchKernelGGL((k_circles_final<EST_UNIT * CAP_SCALE_MAX, VCIRC_UNIT * CAP_SCALE_MAX, false>), dim3(nb * NVAR), dim3(FIN_THREADS),
-                               0, st, g, ctx->d_est_keys, est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc,
+            I2S_LAUNCH(11, (k_circles_final<EST_UNIT * CAP_SCALE_MAX, VCIRC_UNIT * CAP_SCALE_MAX, false>), dim3(nb * NVAR), dim3(FIN_THREADS), g, ctx->d_est_keys, est_count(ctx), cent_count(ctx), p->hc_min_dist, p->hc_min_radius, ctx->d_vcirc,
                                vcount(ctx), overflow(ctx));
         I2S_HIP(hipEventRecord(ctx->ev[2], st));
-        I2S_SEG(12);
+        // -- kernel group 12 of i2s_last_kernel_timing
 
-        hipLaunchKernelGGL(k_concat_circles, dim3(nb), b256, 0, st, ctx->d_desc, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res,
+        I2S_LAUNCH(12, k_concat_circles, dim3(nb), b256, ctx->d_desc, g, ctx->d_vcirc, vcount(ctx), overflow(ctx), ctx->d_res,
                            ctx->d_tl_cnt, ctx->d_tl_idx);
         const int ex = cdiv(wmax, ET_W), ey = cdiv(hmax, ET_H);         // 64 x 64 tiles
-        hipLaunchKernelGGL(k_erase_lines, dim3((unsigned)ex * ey * nb), b256, 0, st, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
+        I2S_LAUNCH(12, k_erase_lines, dim3((unsigned)ex * ey * nb), b256, ctx->d_desc, g, plane_ptr(ctx, I2S_PLANE_EDGES),
                            plane_ptr(ctx, I2S_PLANE_REMOVED), ctx->d_res, trig, ctx->d_lacc, ctx->lrow, ex, ey, ctx->d_tl_cnt, ctx->d_tl_idx);
-        hipLaunchKernelGGL(k_line_peaks, dim3(nb), dim3(LP_THREADS), 0, st, ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
+        I2S_LAUNCH(12, k_line_peaks, dim3(nb), dim3(LP_THREADS), ctx->d_desc, ctx->d_lacc, ctx->lrow, trig, ctx->d_res);
         I2S_HIP(hipEventRecord(ctx->ev[3], st));
-        I2S_SEG(13);
+        // -- kernel group 13 of i2s_last_kernel_timing
 
-        hipLaunchKernelGGL(k_grid, dim3(nb), dim3(GRID_THREADS), 0, st, ctx->d_desc, g, gp, 1, ctx->d_res, ctx->d_boards);
+        I2S_LAUNCH(13, k_grid, dim3(nb), dim3(GRID_THREADS), ctx->d_desc, g, gp, 1, ctx->d_res, ctx->d_boards);
         I2S_HIP(hipEventRecord(ctx->ev[4], st));
-        I2S_SEG(14);
+        // -- kernel group 14 of i2s_last_kernel_timing
 
         I2S_HIP(hipMemcpyAsync(ctx->h_boards, ctx->d_boards, nb * sizeof(i2s_board), hipMemcpyDeviceToHost, st));
         if (ctx->d_sink && dense)
@@ -625,9 +655,9 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     }
     I2S_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]));
     ctx->timing[4] += ms;
-    if (ctx->prof) for (int i = 0; i < I2S_NSEG; i++) {
-        I2S_HIP(hipEventElapsedTime(&ms, ctx->pev[i], ctx->pev[i + 1]));
-        ctx->seg_ms[i] += ms;
+    if (ctx->prof) for (size_t i = 0; i < ctx->prof_used; i++) {
+        I2S_HIP(hipEventElapsedTime(&ms, ctx->prof_pairs[i].start, ctx->prof_pairs[i].stop));
+        ctx->seg_ms[ctx->prof_pairs[i].seg] += ms;
     }
     ctx->last_nb = nb;
     ctx->last_staged = (!p->inputs_on_device || p->contrast >= 0 || p->brightness >= 0) ? 1 : 0;
@@ -940,7 +970,6 @@ extern "C" int i2s_set_profiling(i2s_ctx* ctx, int on)
 {
     if (!ctx) return I2S_E_INVALID;
     I2S_HIP(hipSetDevice(ctx->device));
-    if (on) for (int i = 0; i <= I2S_NSEG; i++) if (!ctx->pev[i]) I2S_HIP(hipEventCreate(&ctx->pev[i]));
     ctx->prof = on ? 1 : 0;
     return I2S_OK;
 }
