@@ -16,7 +16,8 @@ Workload (BASELINE.json configs[2]; configs[3] at --gpus 8): 4096 synthetic 1024
 rank*4096 .. +4095.  The timed region drives `--streams` HIP streams per GPU (independent contexts; the latency-bound
 tail kernels of one slice overlap the throughput-bound kernels of another).  The roofline objects are measured
 separately, right after the timed region, on ONE stream (concurrent streams would stretch every per-kernel duration):
-HIP events recorded on the context's stream in front of every kernel, `--roofline-images` diagrams of the same workload.
+a pair of HIP events per kernel launch on the context's stream, stamped with the kernel's own start and stop (hipExtLaunchKernelGGL: the
+duration a rocprofv3 kernel trace reports), `--roofline-images` diagrams of the same workload.
 """
 import argparse
 import hashlib
@@ -48,7 +49,7 @@ NOISE_SIGMA = 6.0              # SURVEY 8(d) config 2, variant "noisy": N(0, 6^2
 def fixtures_roofline(device, copies=16):
     """The blur+Canny stage on the reference's OWN inputs: the 18 fixtures (tests/golden/test_images: data, committed) after the
     reference's default contrast / brightness step (Pillow on the host, img2sgf.py:136-150), `copies` times, one device pass, one
-    stream, HIP events in front of every kernel.  Real scans are 88-97 % pure black / white PIXELS, but anti-aliased strokes touch
+    stream, HIP start / stop events of every kernel launch.  Real scans are 88-97 % pure black / white PIXELS, but anti-aliased strokes touch
     nearly every 256 x 64 band, so the two-valued speculation of k_blur rarely holds: this, not the synthetic diagrams' figure,
     is what the stage does on a user's files.  Bytes: 14 per processed pixel (SURVEY 8d's unfused accounting, C = 1)."""
     from img2sgf_amd import preprocess
@@ -220,7 +221,7 @@ def main():
     det.close()
 
     if rank == 0:
-        # rooflines: one stream, a HIP event on that stream in front of every kernel
+        # rooflines: one stream, every kernel launch stamped by a pair of HIP events (its own start and stop)
         nr = min(args.roofline_images, B)
         d1 = Detector(local, min(pass_size, nr), 1024, 1024)
         d1.set_profiling(True)
@@ -271,7 +272,8 @@ def main():
                          "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,
                          "stage_us_per_image": stage_s / nr * 1e6,
-                         "measured_on": "1 stream, %d diagrams, HIP events on the context's stream in front of every kernel" % nr},
+                         "measured_on": "1 stream, %d diagrams, HIP start / stop events of every kernel launch on the context's stream "
+                                        "(hipExtLaunchKernelGGL): kernel durations, as in a rocprofv3 kernel trace" % nr},
             "roofline_noisy": {"bound": "hbm", "kernel": "blur+Canny stage on the noisy variant of the workload (N(0, %g^2) added, clipped)" % NOISE_SIGMA,
                                "achieved": ach_noisy, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_noisy / HBM_PEAK_GBS,
                                "traffic": None, "algorithmic_bytes_per_image": BLUR_CANNY_BYTES,

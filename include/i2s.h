@@ -317,8 +317,9 @@ int  i2s_set_board_sink(i2s_ctx* ctx, i2s_board* d_sink);
 int  i2s_allgather_boards(i2s_ctx* ctx, i2s_comm* comm, const i2s_board* d_boards, int n_local,
                           i2s_board* d_all, i2s_board* h_all);
 
-/* Per-kernel timing (bench.py's roofline objects): with profiling on, a detect call records one HIP event on the
- * context's stream in front of every kernel group; i2s_last_kernel_timing returns the milliseconds each of the
+/* Per-kernel timing (bench.py's roofline objects): with profiling on, every kernel launch of a detect call is stamped with a pair of
+ * HIP events on the context's stream -- the kernel's own start and stop (hipExtLaunchKernelGGL), i.e. the duration a rocprofv3
+ * kernel trace reports, without the dispatch gaps between kernels; i2s_last_kernel_timing returns the milliseconds each of the
  * I2S_NSEG groups took, summed over the passes of the last detect call; i2s_kernel_timing_name(i) names group i. */
 #define I2S_NSEG 14
 int  i2s_set_profiling(i2s_ctx* ctx, int on);

@@ -95,7 +95,11 @@ def main():
         "round 4 the main Canny runs first and k_blur re-reads the sources it left in that cache (deliberately: profiles/r04_b_blur_experiments.txt),",
         "so part of k_blur's source reads never reach HBM; the plane traffic (12 of the 14 N) is far beyond any cache.", ""]
     if len(sys.argv) > 2 and os.path.exists(sys.argv[2]):
-        b = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+        txt = open(sys.argv[2]).read()
+        try:
+            b = json.loads(txt)                                    # a pretty-printed copy under profiles/
+        except ValueError:
+            b = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])      # bench.py's own output
         md += ["## against the bench line (`%s`)" % os.path.relpath(os.path.abspath(sys.argv[2]), ROOT), "",
                "| | bench line (HIP events on the stream, one pass of 256) | from the traces above | ratio |", "|---|---|---|---|"]
         for name, bv, tv in (("roofline.frac", b["roofline"]["frac"], N14 / sc / 1e6 / 8.0),
