@@ -899,6 +899,20 @@ __device__ __forceinline__ void bs_planes_to_bytes(const unsigned (&pl)[8], unsi
     }
 }
 
+// A thread's 24 output bytes of one row.  The planes have a 64-byte pitch (whole dwords may be written) and xo is a multiple of 8: three
+// 8-byte stores where the row has all 24 pixels (the wavefront's 64 lanes are 64 different ROWS, so every store instruction touches
+// 64 cache lines: half as many instructions as dword stores, 3.84 -> 3.57 us per noisy diagram; without any store the kernel takes 3.08), dword stores at the image's right edge.
+__device__ __forceinline__ void bs_store24(uint8_t* p, const unsigned (&o)[6], int xo, int w)
+{
+    if (xo + 20 < w) {
+        uint2* q = reinterpret_cast<uint2*>(p);
+        q[0] = make_uint2(o[0], o[1]); q[1] = make_uint2(o[2], o[3]); q[2] = make_uint2(o[4], o[5]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (xo + 4 * k < w) *reinterpret_cast<unsigned*>(p + 4 * k) = o[k];
+    }
+}
+
 // The general kernel.  flags (optional): the band flags of k_median57_bin; a tile none of whose bands is flagged has exact
 // medians already.  A workgroup looks at M_TPB consecutive tiles of the (plane, row-major tile) sequence: on two-valued
 // diagrams all it does is read their flags, one tile per lane (one workgroup per tile, or one tile after the other, spent
@@ -1025,15 +1039,11 @@ __global__ __launch_bounds__(256, M_WAVES) void k_median57(const ImgDesc* __rest
             bs_median_row<7>(s_pl, row, 24 * half, nlive, live_list, s_src);
             bs_collect(s_src, live, 1, res);                               // window bit 4 (the first output) sits at bit 4 - 3
             bs_planes_to_bytes(res, o);
-#pragma unroll
-            for (int q = 0; q < 6; q++)                                    // planes have a 64-byte pitch: whole dwords may be written
-                if (xo + 4 * q < w) *reinterpret_cast<unsigned*>(p7 + 4 * q) = o[q];
+            bs_store24(p7, o, xo, w);
             bs_median_row<5>(s_pl, row, 24 * half, nlive, live_list, s_src);
             bs_collect(s_src, live, 2, res);
             bs_planes_to_bytes(res, o);
-#pragma unroll
-            for (int q = 0; q < 6; q++)
-                if (xo + 4 * q < w) *reinterpret_cast<unsigned*>(p5 + 4 * q) = o[q];
+            bs_store24(p5, o, xo, w);
         }
         if (kn < 0) break;
         k = kn;
