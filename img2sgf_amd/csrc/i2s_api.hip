@@ -93,6 +93,7 @@ struct i2s_ctx {
     int* d_chg = nullptr;        // hysteresis revisit queues: [2 (pass parity)][NMAP * nb * tiles] tile keys
     int* d_hmark = nullptr;      // [NMAP][nb][tiles] stamp of the latest pass a tile was queued for (hy_stamp + pass + 1; only ever grows)
     int hy_stamp = 0;            // advanced by HYST_MAX_PASSES + 2 per phase run
+    int* d_colour = nullptr;     // [nb] k_grey: the 3-channel image holds a pixel whose channels differ (else it is treated as grey)
     int* d_mflags = nullptr;     // [nb][bands_y][bands_x] k_median57_bin: the band holds a pixel other than 0 / 255
     uint2* d_bin_ent = nullptr;
     int* d_bin_cnt = nullptr;
@@ -193,7 +194,7 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_hmark, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_hmark, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_colour, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
     for (void* q : dev) if (q) (void)hipFree(q);
     void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob, ctx->h_coef.p};
     for (void* q : host) if (q) (void)hipHostFree(q);
@@ -239,6 +240,7 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipMalloc(&ctx->d_hmark, nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMemset(ctx->d_hmark, 0, nb * NMAP * g.tiles * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_mflags, nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_colour, nb * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_planes, (size_t)NPLANES * nb * g.slot + 256));
     ctx->src_slot = (size_t)ctx->max_w * 3 * ctx->max_h;
     I2S_HIP(hipMalloc(&ctx->d_src, nb * ctx->src_slot + 256));
@@ -489,12 +491,13 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipMemsetAsync(worklist(ctx, 1), 0, sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_lacc, 0, (size_t)nb * LROWS * ctx->lrow * sizeof(int), st));
         I2S_HIP(hipMemsetAsync(ctx->d_mflags, 0, (size_t)nb * mb_bands_x(g.wmax) * mb_bands_y(g.hmax) * sizeof(int), st));
+        I2S_HIP(hipMemsetAsync(ctx->d_colour, 0, (size_t)nb * sizeof(int), st));
         uint8_t* grey = plane_ptr(ctx, I2S_PLANE_GREY);
         uint8_t* map0 = plane_ptr(ctx, I2S_PLANE_CANNY_MAP);
         uint8_t* edges = plane_ptr(ctx, I2S_PLANE_EDGES);
         const dim3 b64x4(64, 4), b256(256);
         // tile grids of this pass (1-D launches, XCD-aware tile order inside the kernels)
-        const int rx = cdiv(wmax, 256), ry = cdiv(hmax, 4);            // row kernels: 256 x 4 pixels per workgroup
+        const int rx = cdiv(wmax, 256), ry = cdiv(hmax, GREY_ROWS);    // k_grey / k_split_rgb: 256 x GREY_ROWS pixels per workgroup
         const int fx = cdiv(wmax, FT_W), fy = cdiv(hmax, FT_H);        // 64 x 32 tiles
         const int mx = cdiv(wmax, MT_W), my = cdiv(hmax, MT_H);        // 56 x 72 tiles
         const int ebx = cdiv(wmax, EBB_X * EB), eby = cdiv(hmax, EBB_Y * EB);      // 128 x 32 (4 x 1 edge bins)
@@ -503,23 +506,35 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
         // -- kernel group 0 of i2s_last_kernel_timing
-        if (need_grey) I2S_LAUNCH(0, k_grey, g_row, b64x4, ctx->d_desc, g, grey, p->grey_shift, rx, ry);
+        if (need_grey) I2S_LAUNCH(0, k_grey, g_row, b64x4, ctx->d_desc, g, grey, p->grey_shift, ctx->d_colour, rx, ry);
         // Order of the two independent halves of the blur+Canny stage (round 4): the main Canny FIRST.  It is bound by its arithmetic and
         // does not care where the grey source comes from; k_blur is bound by its six plane stores, and those stream ~15 % faster when
         // the source it reads at the same time is already in the Infinity Cache than when HBM has to turn around between reads and
         // writes (profiles/r04_b_blur_experiments.txt: 1.92 -> 1.69 us per diagram with the source read by a kernel in front of it).
         // The main Canny and HoughCircles' internal Canny of the grey plane share everything but the high threshold when
         // their low thresholds coincide (the reference's 50 and 100 / 2): one kernel pass then writes both maps.
-        const bool fused0 = has_c1 && p->canny_lo == hc_lo;
+        // (3-channel images whose channels are equal everywhere -- greyscale scans opened as RGB -- take the single-channel kernel too:
+        // k_grey has just found out which, d_colour)
+        const bool rows_main = has_c1 || has_c3;
+        const bool fused0 = rows_main && p->canny_lo == hc_lo;
         // -- kernel group 1 of i2s_last_kernel_timing
         const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
         if (fused0)
             I2S_LAUNCH(1, (k_sobel_nms_rows<2>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
-                               p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
-        else if (has_c1)
+                               p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
+        else if (rows_main)
             I2S_LAUNCH(1, (k_sobel_nms_rows<1>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0,
-                               p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
-        if (has_c3) I2S_LAUNCH(1, (k_sobel_nms_src<3>), g_f, b256, ctx->d_desc, g, map0, edges, p->canny_lo, p->canny_hi, worklist(ctx, 0), fx, fy);
+                               p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
+        if (has_c3) {
+            // coloured images (d_colour): their channels as three planes in the slots of the blur bank that are still free (median3, gauss3,
+            // median5: consecutive), then the row kernel's colour mode (round 1's LDS-tile kernel took 680 us for the reference's nine colour
+            // scans x 16, this pair 580; k_grey / k_split_rgb with 32 rows per workgroup instead of 4: 291 -> 166 us)
+            static_assert(I2S_PLANE_GAUSS3 == I2S_PLANE_MEDIAN3 + 1 && I2S_PLANE_MEDIAN5 == I2S_PLANE_MEDIAN3 + 2, "three consecutive scratch planes");
+            uint8_t* rgb = plane_ptr(ctx, I2S_PLANE_MEDIAN3);
+            I2S_LAUNCH(1, k_split_rgb, g_row, b64x4, ctx->d_desc, g, rgb, ctx->d_colour, rx, ry);
+            I2S_LAUNCH(1, (k_sobel_nms_rows<3>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, rgb, map0, edges, 0, p->canny_lo,
+                       p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
+        }
         // -- kernel group 2 of i2s_last_kernel_timing
         rc = run_hysteresis(ctx, 0, fx * fy * nb);
         if (rc) return rc;
@@ -560,7 +575,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         // -- kernel group 6 of i2s_last_kernel_timing
         const int v_first = fused0 ? 1 : 0;
         I2S_LAUNCH(6, (k_sobel_nms_rows<0>), dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, ctx->d_desc, g, grey, map0,
-                           (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, worklist(ctx, 1), worklist(ctx, 0), cgx, cgy);
+                           (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
         // -- kernel group 7 of i2s_last_kernel_timing
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;

@@ -14,108 +14,6 @@ constexpr int CT_H = 32;
 // hysteresis works on the same 64 x 32 tiles.  Tiles that hold weak pixels are appended to a worklist by the NMS kernels:
 // wl[0] = count, wl[1 + i] = (m * nb + b) * g.tiles + ty * g.tw + tx; only those tiles are ever visited again.
 
-// Sobel + NMS of one tile.  src(y,x,c) = sp[y*sstride + x*CN + c].
-template <int CN>
-__device__ __forceinline__ void sobel_nms_tile(const uint8_t* __restrict__ sp, int sstride, int w, int h,
-                                               int low, int high, uint8_t* __restrict__ mp, uint8_t* __restrict__ ep, int mpitch,
-                                               int* __restrict__ weak_wl, int weak_key, int tile_x, int tile_y)
-{
-    __shared__ int s_weak;
-    constexpr int SW = CT_W + 4, SH = CT_H + 4;   // source tile with 2-px apron
-    constexpr int MW = CT_W + 2, MH = CT_H + 2;   // gradient tile with 1-px apron
-    __shared__ __attribute__((aligned(4))) uint8_t s_src[SH][SW * CN + 4];
-    __shared__ short s_dx[MH][MW], s_dy[MH][MW];
-    __shared__ unsigned short s_mag[MH][MW];
-    const int x0 = tile_x * CT_W, y0 = tile_y * CT_H;
-    if (x0 >= w || y0 >= h) return;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_weak = 0;
-    if ((SW * CN) % 4 == 0 && x0 - 2 >= 0 && x0 - 2 + SW <= w && y0 - 2 >= 0 && y0 - 2 + SH <= h) {
-        // tile (with its apron) wholly inside the image: rows of SW * CN bytes as (unaligned) dword loads -- byte loads of
-        // interleaved channels keep the texture-address unit busy for 4x as many instructions
-        constexpr int RW = SW * CN / 4;
-        for (int i = tid; i < SH * RW; i += 256) {
-            const int ly = i / RW, c4 = i - ly * RW;
-            unsigned v;
-            __builtin_memcpy(&v, sp + (size_t)(y0 + ly - 2) * sstride + (size_t)(x0 - 2) * CN + 4 * c4, 4);
-            *reinterpret_cast<unsigned*>(&s_src[ly][4 * c4]) = v;
-        }
-    } else {
-        for (int i = tid; i < SH * SW; i += 256) {
-            const int ly = i / SW, lx = i - ly * SW;
-            const int gy = iclamp(y0 + ly - 2, 0, h - 1), gx = iclamp(x0 + lx - 2, 0, w - 1);
-            const uint8_t* p = sp + (size_t)gy * sstride + (size_t)gx * CN;
-#pragma unroll
-            for (int c = 0; c < CN; c++) s_src[ly][lx * CN + c] = p[c];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < MH * MW; i += 256) {
-        const int ly = i / MW, lx = i - ly * MW;
-        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        int bdx = 0, bdy = 0, bm = 0;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-#pragma unroll
-            for (int c = 0; c < CN; c++) {
-                // centre of the 3x3 window in s_src is (ly+1, lx+1)
-                const int a = s_src[ly][lx * CN + c], bb = s_src[ly][(lx + 1) * CN + c], cc = s_src[ly][(lx + 2) * CN + c];
-                const int d = s_src[ly + 1][lx * CN + c], f = s_src[ly + 1][(lx + 2) * CN + c];
-                const int gg = s_src[ly + 2][lx * CN + c], hh = s_src[ly + 2][(lx + 1) * CN + c], ii = s_src[ly + 2][(lx + 2) * CN + c];
-                const int dx = (cc + 2 * f + ii) - (a + 2 * d + gg);
-                const int dy = (gg + 2 * hh + ii) - (a + 2 * bb + cc);
-                const int m = iabs_(dx) + iabs_(dy);
-                if (c == 0 || m > bm) { bdx = dx; bdy = dy; bm = m; }
-            }
-        }
-        s_dx[ly][lx] = (short)bdx; s_dy[ly][lx] = (short)bdy; s_mag[ly][lx] = (unsigned short)bm;
-    }
-    __syncthreads();
-    for (int i = tid; i < CT_H * CT_W; i += 256) {
-        const int ly = i / CT_W, lx = i - ly * CT_W;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= w || gy >= h) continue;
-        const int cy = ly + 1, cx = lx + 1;
-        const int m = s_mag[cy][cx];
-        uint8_t out = 1;
-        if (m > low) {
-            const int xs = s_dx[cy][cx], ys = s_dy[cy][cx];
-            const int ax = iabs_(xs), ay = iabs_(ys) << 15;
-            const int tg22x = ax * 13573;
-            bool keep;
-            if (ay < tg22x) {
-                keep = m > s_mag[cy][cx - 1] && m >= s_mag[cy][cx + 1];
-            } else {
-                const int tg67x = tg22x + (ax << 16);
-                if (ay > tg67x) {
-                    keep = m > s_mag[cy - 1][cx] && m >= s_mag[cy + 1][cx];
-                } else {
-                    const int s = ((xs ^ ys) < 0) ? -1 : 1;
-                    keep = m > s_mag[cy - 1][cx - s] && m > s_mag[cy + 1][cx + s];
-                }
-            }
-            if (keep) out = (m > high) ? 2 : 0;
-        }
-        mp[(size_t)gy * mpitch + gx] = out;
-        ep[(size_t)gy * mpitch + gx] = out == 2 ? 255 : 0;      // the edge image (img2sgf.py:162); hysteresis adds the promoted pixels
-        if (out == 0) s_weak = 1;
-    }
-    __syncthreads();
-    if (tid == 0 && s_weak) weak_wl[1 + atomicAdd(&weak_wl[0], 1)] = weak_key;
-}
-
-// Main Canny (map 0) on COLOUR source images (single-channel planes go through k_sobel_nms_rows, k_canny_rows.h): grid (tiles_x, tiles_y, nb).
-template <int CN>
-__global__ __launch_bounds__(256) void k_sobel_nms_src(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ map0,
-                                                       uint8_t* __restrict__ edges, int low, int high, int* __restrict__ weak,
-                                                       int gx, int gy)
-{
-    const TileId t = tile_of_block(gx, gy);
-    const int b = t.z;
-    const ImgDesc im = desc[b];
-    if (im.cn != CN) return;
-    sobel_nms_tile<CN>(im.src, im.sstride, im.w, im.h, low, high, map0 + (size_t)b * g.slot, edges + (size_t)b * g.slot, g.pitch,
-                       weak, (int)((size_t)b * g.tiles + (size_t)t.ty * g.tw + t.tx), t.tx, t.ty);
-}
 
 // One hysteresis pass over the tiles of a worklist (all maps of the phase).  A fixed, small grid of workgroups strides over
 // the list, one WAVEFRONT per listed 64x32 tile: lane r holds row y0 - 1 + r of the tile (rows -1 and 32 are the read-only

@@ -43,20 +43,27 @@ __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned 
 }
 
 // main_mode: 0 = HoughCircles' Canny of variants v_first .. (plane v -> map 1 + v), 1 = main Canny of grey
-// sources (plane 0 -> map 0 + edge image, threshold high_main), 2 = both at once for the grey plane.
+// sources (plane 0 -> map 0 + edge image, threshold high_main), 2 = both at once for the grey plane, 3 = main Canny of COLOURED
+// sources (round 4): the R, G, B planes k_split_rgb wrote (`planes` + c * nb * slot), per pixel the gradient of the channel with the
+// largest L1 magnitude, ties to the lower index (OpenCV canny.cpp, Appendix A.2 step 2) -- the Sobel part three times, everything
+// behind it once; images whose channels are equal everywhere (has_colour == 0) have been done in mode 1 / 2.
 // grid: ceil(w / 1024) x ceil(h / CR_R) x (nb * variants) workgroups of 4 wavefronts (4 consecutive 256-pixel column groups).
 template <int main_mode>
 __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
                                                         uint8_t* __restrict__ maps, uint8_t* __restrict__ edges, int v_first, int low,
                                                         int high, int high_main, int* __restrict__ weak,
-                                                        int* __restrict__ weak_main, int gx, int gy)
+                                                        int* __restrict__ weak_main, const int* __restrict__ has_colour, int gx, int gy)
 {
     const TileId tl = tile_of_block(gx, gy);
     const int b = tl.z % g.nb;
     const int v = main_mode ? 0 : v_first + tl.z / g.nb;
+    constexpr int NC = main_mode == 3 ? 3 : 1;                     // channels whose gradients compete
     const ImgDesc im = desc[b];
-    if (main_mode == 1 && im.cn != 1) return;
-    const bool main_out = main_mode != 0 && im.cn == 1;            // writes map 0 + edges
+    // the main Canny of an image runs here, on its grey plane, unless the image really is coloured (k_grey's has_colour: see there)
+    const bool grey_like = im.cn == 1 || (main_mode != 0 && has_colour[b] == 0);
+    if (main_mode == 1 && !grey_like) return;
+    if (main_mode == 3 && grey_like) return;
+    const bool main_out = main_mode != 0 && (grey_like || main_mode == 3);     // writes map 0 + edges
     if (main_mode == 1) high = high_main;
     const int w = im.w, h = im.h;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -65,13 +72,16 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     const int y0 = tl.ty * CR_R;
     if (cgp * 256 >= w || y0 >= h) return;
     const bool active = x0 < w;
-    const uint8_t* plane = v == 0 ? im.grey : planes + ((size_t)v * g.nb + b) * g.slot;
-    const int sp = v == 0 ? im.gpitch : g.pitch;
-    const int m_first = main_mode == 1 ? 0 : 1 + v;
+    const uint8_t* plane = main_mode == 3 ? planes + (size_t)b * g.slot : (v == 0 ? im.grey : planes + ((size_t)v * g.nb + b) * g.slot);
+    const int sp = (v == 0 && main_mode != 3) ? im.gpitch : g.pitch;
+    const int m_first = (main_mode == 1 || main_mode == 3) ? 0 : 1 + v;
     uint8_t* mp = maps + ((size_t)m_first * g.nb + b) * g.slot;
     uint8_t* mp0 = (main_mode == 2 && main_out) ? maps + (size_t)b * g.slot : nullptr;
     uint8_t* ep = main_out ? edges + (size_t)b * g.slot : nullptr;
-    const BlBuf pbuf = bl_buf(plane), mbuf = bl_buf(mp), m0buf = bl_buf(mp0 ? mp0 : mp), ebuf = bl_buf(ep ? ep : mp);
+    BlBuf pbuf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) pbuf[c] = bl_buf(plane + (size_t)c * g.nb * g.slot);
+    const BlBuf mbuf = bl_buf(mp), m0buf = bl_buf(mp0 ? mp0 : mp), ebuf = bl_buf(ep ? ep : mp);
     CrThr th;
     th.lowp = (unsigned)(iclamp(low, -1, 4095) & 0xffff) * 0x00010001u;
     th.highp = (unsigned)(iclamp(high, -1, 4095) & 0xffff) * 0x00010001u;
@@ -108,22 +118,26 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     const bool has_e = (lane == 0 && x0 >= 4) || (lane == 63 && x0 + 4 < w);
     const unsigned xm = active ? (unsigned)x0 : 0u, xeo = has_e ? (unsigned)(lane == 0 ? x0 - 4 : x0 + 4) : 0u;
 
-    unsigned PA[3], PB[3], PC[3], PE[3];            // pixel pairs (-1,0), (1,2), (3,4) and the end-lane bytes of the last 3 input rows
+    unsigned PA[NC][3], PB[NC][3], PC[NC][3], PE[NC][3];   // per channel: pixel pairs (-1,0), (1,2), (3,4) and the end-lane bytes of the last 3 input rows
     // magnitudes of the last 3 gradient rows: the own pairs (pixels 0,1 and 2,3) and the same row shifted by one pixel --
     // (-1,0), (1,2), (3,4), formed ONCE per row from the neighbour lanes' pairs (each row is used by three suppressions)
     unsigned M01[3], M23[3], SL[3], SM[3], SR[3];
     // of the last 2 gradient rows: |dx|, |dy| and the mask "signs differ" (the suppression needs nothing else of the gradients)
     unsigned AX01[2], AX23[2], AY01[2], AY23[2], SG01[2], SG23[2];
 #pragma unroll
-    for (int i = 0; i < 3; i++) { PA[i] = PB[i] = PC[i] = PE[i] = 0; M01[i] = M23[i] = SL[i] = SM[i] = SR[i] = 0; }
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) PA[c][i] = PB[c][i] = PC[c][i] = PE[c][i] = 0;
+        M01[i] = M23[i] = SL[i] = SM[i] = SR[i] = 0;
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++) { AX01[i] = AX23[i] = AY01[i] = AY23[i] = SG01[i] = SG23[i] = 0; }
 
-    unsigned nM, nE;
+    unsigned nM[NC], nE[NC];
     {
         const int ro = rowoff(iclamp(y0 - 2, 0, h - 1), sp);
-        nM = bl_bload(pbuf, ro, xm);
-        nE = bl_bload(pbuf, ro, xeo);
+#pragma unroll
+        for (int c = 0; c < NC; c++) { nM[c] = bl_bload(pbuf[c], ro, xm); nE[c] = bl_bload(pbuf[c], ro, xeo); }
     }
     unsigned wk_acc = 0, wk0_acc = 0;
     static_assert((CR_R + 4) % 6 == 0, "the row loop is unrolled by the ring depths (3 and 2)");
@@ -133,37 +147,44 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
         for (int u = 0; u < 6; u++) {
             const int t = t0 + u;
             const int yi = y0 - 2 + t;                                 // input row (clamped when outside)
-            const unsigned M = nM, E = nE;
+            unsigned Mc[NC], Ec[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) { Mc[c] = nM[c]; Ec[c] = nE[c]; }
             {
                 const int ro = rowoff(iclamp(yi + 1, 0, h - 1), sp);
-                nM = bl_bload(pbuf, ro, xm);
-                nE = bl_bload(pbuf, ro, xeo);
-            }
-            unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E), Mf = M;
-            if (fix) {
-                BL_KEEP_BRANCH();
-                const unsigned l2 = __builtin_amdgcn_perm(M, L, sL), m2 = __builtin_amdgcn_perm(M, L, sM), r2 = __builtin_amdgcn_perm(R, M, sR);
-                L = l2; Mf = m2; R = r2;
+#pragma unroll
+                for (int c = 0; c < NC; c++) { nM[c] = bl_bload(pbuf[c], ro, xm); nE[c] = bl_bload(pbuf[c], ro, xeo); }
             }
             const int ps = u % 3;                                      // ring slot of this input row
-            PA[ps] = __builtin_amdgcn_perm(Mf, L, 0x0c040c03u);
-            PB[ps] = __builtin_amdgcn_perm(Mf, Mf, 0x0c020c01u);
-            PC[ps] = __builtin_amdgcn_perm(R, Mf, 0x0c040c03u);
-            PE[ps] = __builtin_amdgcn_perm(e_hi ? R : Mf, e_hi ? Mf : L, eS);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const unsigned M = Mc[c], E = Ec[c];
+                unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E), Mf = M;
+                if (fix) {
+                    BL_KEEP_BRANCH();
+                    const unsigned l2 = __builtin_amdgcn_perm(M, L, sL), m2 = __builtin_amdgcn_perm(M, L, sM), r2 = __builtin_amdgcn_perm(R, M, sR);
+                    L = l2; Mf = m2; R = r2;
+                }
+                PA[c][ps] = __builtin_amdgcn_perm(Mf, L, 0x0c040c03u);
+                PB[c][ps] = __builtin_amdgcn_perm(Mf, Mf, 0x0c020c01u);
+                PC[c][ps] = __builtin_amdgcn_perm(R, Mf, 0x0c040c03u);
+                PE[c][ps] = __builtin_amdgcn_perm(e_hi ? R : Mf, e_hi ? Mf : L, eS);
+            }
             // gradient row yg = yi - 1 from input rows yi - 2, yi - 1, yi (slots ps + 1, ps + 2, ps)
             const int yg = yi - 1;
             const int gs = u % 3;                                      // magnitude ring slot of gradient row yg (same phase as ps)
             const int g2 = u % 2;                                      // gradient ring slot
             if (t >= 2) {
                 const int top = (u + 1) % 3, mid = (u + 2) % 3, bot = ps;
-                unsigned dx01, dx23, dy01, dy23, mg01, mg23, mge;
+                unsigned dx01 = 0, dx23 = 0, dy01 = 0, dy23 = 0, mg01 = 0, mg23 = 0, mge = 0;
                 // gradient rows outside the image (yg = -1, h) are zero: folded into the column masks (a branch around the block
                 // costs seven register clears on every row for the sake of two rows per image)
                 const unsigned rowm = (yg >= 0 && yg < h) ? 0xffffffffu : 0u;
-                {
-                    const v2s ta = pk_from(PA[top]), tb = pk_from(PB[top]), tc = pk_from(PC[top]);
-                    const v2s ma = pk_from(PA[mid]), mb = pk_from(PB[mid]), mc = pk_from(PC[mid]);
-                    const v2s ba = pk_from(PA[bot]), bb = pk_from(PB[bot]), bc = pk_from(PC[bot]);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const v2s ta = pk_from(PA[c][top]), tb = pk_from(PB[c][top]), tc = pk_from(PC[c][top]);
+                    const v2s ma = pk_from(PA[c][mid]), mb = pk_from(PB[c][mid]), mc = pk_from(PC[c][mid]);
+                    const v2s ba = pk_from(PA[c][bot]), bb = pk_from(PB[c][bot]), bc = pk_from(PC[c][bot]);
                     const v2s ca = ta + ma + ma + ba, cb = tb + mb + mb + bb, cc = tc + mc + mc + bc;
                     const v2s da = ba - ta, db = bb - tb, dc = bc - tc;
                     const v2s x01 = cb - ca, x23 = cc - cb;
@@ -171,20 +192,30 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                     const v2s m23 = pk_from(__builtin_amdgcn_alignbit(pk_bits(dc), pk_bits(db), 16));    // (dif2, dif3)
                     const v2s y01 = da + m01 + m01 + db, y23 = db + m23 + m23 + dc;
                     const unsigned r01 = k01 & rowm, r23 = k23 & rowm;
-                    dx01 = pk_bits(x01) & r01; dy01 = pk_bits(y01) & r01;
-                    dx23 = pk_bits(x23) & r23; dy23 = pk_bits(y23) & r23;
-                    const unsigned ax01 = pk_bits(pk_abs(pk_from(dx01))), ay01 = pk_bits(pk_abs(pk_from(dy01)));
-                    const unsigned ax23 = pk_bits(pk_abs(pk_from(dx23))), ay23 = pk_bits(pk_abs(pk_from(dy23)));
-                    mg01 = pk_bits(pk_from(ax01) + pk_from(ay01));
-                    mg23 = pk_bits(pk_from(ax23) + pk_from(ay23));
-                    AX01[g2] = ax01; AX23[g2] = ax23; AY01[g2] = ay01; AY23[g2] = ay23;
-                    SG01[g2] = pk_bits(pk_from(dx01 ^ dy01) >> 15); SG23[g2] = pk_bits(pk_from(dx23 ^ dy23) >> 15);
+                    const unsigned cdx01 = pk_bits(x01) & r01, cdy01 = pk_bits(y01) & r01;
+                    const unsigned cdx23 = pk_bits(x23) & r23, cdy23 = pk_bits(y23) & r23;
+                    const unsigned cm01 = pk_bits(pk_abs(pk_from(cdx01)) + pk_abs(pk_from(cdy01)));
+                    const unsigned cm23 = pk_bits(pk_abs(pk_from(cdx23)) + pk_abs(pk_from(cdy23)));
                     // end lanes: magnitude at column xe from bytes (xe - 1, xe, xe + 1) of the three rows
-                    const unsigned et = PE[top], em = PE[mid], eb = PE[bot];
+                    const unsigned et = PE[c][top], em = PE[c][mid], eb = PE[c][bot];
                     const int sc = (int)__builtin_amdgcn_udot4(et, 0x00010000u, __builtin_amdgcn_udot4(em, 0x00020000u, __builtin_amdgcn_udot4(eb, 0x00010000u, 0u, false), false), false);
                     const int sa = (int)__builtin_amdgcn_udot4(et, 0x00000001u, __builtin_amdgcn_udot4(em, 0x00000002u, __builtin_amdgcn_udot4(eb, 0x00000001u, 0u, false), false), false);
                     const int edy = (int)__builtin_amdgcn_udot4(eb, 0x00010201u, 0u, false) - (int)__builtin_amdgcn_udot4(et, 0x00010201u, 0u, false);
-                    mge = e_ok ? (unsigned)(iabs_(sc - sa) + iabs_(edy)) & rowm : 0u;
+                    const unsigned cme = e_ok ? (unsigned)(iabs_(sc - sa) + iabs_(edy)) & rowm : 0u;
+                    if (c == 0) { dx01 = cdx01; dy01 = cdy01; dx23 = cdx23; dy23 = cdy23; mg01 = cm01; mg23 = cm23; mge = cme; }
+                    else {
+                        // a later channel wins only with a strictly larger magnitude (per pixel: the 16-bit halves decide separately)
+                        const unsigned w01 = pk_gt(cm01, mg01), w23 = pk_gt(cm23, mg23);
+                        dx01 = bsel(w01, cdx01, dx01); dy01 = bsel(w01, cdy01, dy01); mg01 = bsel(w01, cm01, mg01);
+                        dx23 = bsel(w23, cdx23, dx23); dy23 = bsel(w23, cdy23, dy23); mg23 = bsel(w23, cm23, mg23);
+                        mge = cme > mge ? cme : mge;
+                    }
+                }
+                {
+                    const unsigned ax01 = pk_bits(pk_abs(pk_from(dx01))), ay01 = pk_bits(pk_abs(pk_from(dy01)));
+                    const unsigned ax23 = pk_bits(pk_abs(pk_from(dx23))), ay23 = pk_bits(pk_abs(pk_from(dy23)));
+                    AX01[g2] = ax01; AX23[g2] = ax23; AY01[g2] = ay01; AY23[g2] = ay23;
+                    SG01[g2] = pk_bits(pk_from(dx01 ^ dy01) >> 15); SG23[g2] = pk_bits(pk_from(dx23 ^ dy23) >> 15);
                 }
                 M01[gs] = mg01; M23[gs] = mg23;
                 // pair (x0 - 2, x0 - 1) of the left neighbour and pair (x0 + 4, x0 + 5) of the right one (only their inner halves are used)
@@ -218,7 +249,8 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
             }
             // stores after the wait for the prefetched row (see BL_CONSUME in k_filters.h)
             BL_SCHED_FENCE();
-            BL_CONSUME(nM, nE);
+#pragma unroll
+            for (int c = 0; c < NC; c++) BL_CONSUME(nM[c], nE[c]);
             BL_SCHED_FENCE();
             if (emit && active) {
                 const int off = rowoff(yn, g.pitch);
@@ -232,7 +264,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                 if ((lane & 15) == 0) {
                     const int tile_x = cgp * 4 + (lane >> 4), tile_y = yn / CT_H;
                     const unsigned long long grp = 0xffffull << lane;
-                    int* weak_first = main_mode == 1 ? weak_main : weak;
+                    int* weak_first = (main_mode == 1 || main_mode == 3) ? weak_main : weak;
                     if (bw & grp) weak_first[1 + atomicAdd(&weak_first[0], 1)] = (int)(((size_t)m_first * g.nb + b) * g.tiles + (size_t)tile_y * g.tw + tile_x);
                     if (bw0 & grp) weak_main[1 + atomicAdd(&weak_main[0], 1)] = (int)((size_t)b * g.tiles + (size_t)tile_y * g.tw + tile_x);
                 }

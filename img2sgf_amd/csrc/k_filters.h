@@ -16,21 +16,29 @@ constexpr int FT_H = 32;
 
 // ---- K1: grey plane.  cn==1: copy; cn==3: (ch0*B + ch1*G + ch2*R + half) >> shift, where the
 // reference hands RGB data to COLOR_BGR2GRAY, so ch0 (=R) is weighted as "blue" (img2sgf.py:153).
-// block (64,4), each thread 4 pixels.
-__global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ grey, int shift, int gx, int gy)
+// block (64,4), each thread 4 pixels of GREY_ROWS / 4 rows (a workgroup of 256 x 4 pixels, as in rounds 1-3, is 450 000 workgroups for a
+// pass of 288 scans: the kernel was bound by their dispatch, 1.9 us per megapixel).
+constexpr int GREY_ROWS = 32;
+// has_colour[b] (zeroed by the host) is raised when a 3-channel image holds a pixel whose channels differ.  The reference hands EVERY input
+// over as RGB (Image.open(...).convert("RGB"), img2sgf.py:651), also the greyscale scans that are most of its inputs: with R = G = B the
+// grey value is that value under either set of weights and the 3-channel Canny picks channel 0 of three identical gradients, so such an
+// image goes through the single-channel kernels (k_sobel_nms_rows on its grey plane) bit for bit.
+__global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ grey, int shift, int* __restrict__ has_colour,
+                                              int gx, int gy)
 {
     const TileId t = tile_of_block(gx, gy);
     const int b = t.z;
     const ImgDesc im = desc[b];
     if (im.grey == im.src) return;                                   // the source is the grey plane (see ImgDesc)
-    const int y = t.ty * 4 + threadIdx.y;
     const int x0 = (t.tx * 64 + threadIdx.x) * 4;
-    if (y >= im.h || x0 >= im.w) return;
-    const uint8_t* s = im.src + (size_t)y * im.sstride;
-    uint8_t* o = grey + (size_t)b * g.slot + rowoff(y, g.pitch);
+    if (x0 >= im.w) return;
     int cb, cg, cr;
     if (shift == 14) { cb = 1868; cg = 9617; cr = 4899; } else { cb = 3735; cg = 19235; cr = 9798; }
     const int half = 1 << (shift - 1);
+    bool coloured = false;
+    for (int y = t.ty * GREY_ROWS + threadIdx.y; y < imin((t.ty + 1) * GREY_ROWS, im.h); y += 4) {
+    const uint8_t* s = im.src + (size_t)y * im.sstride;
+    uint8_t* o = grey + (size_t)b * g.slot + rowoff(y, g.pitch);
     if (x0 + 3 < im.w) {
         // whole dwords; the source may start anywhere (odd-width RGB rows): the loads are unaligned dword loads
         unsigned out;
@@ -43,15 +51,56 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
             const unsigned g2 = (((d1 >> 16) & 0xffu) * cb + (d1 >> 24) * cg + (d2 & 0xffu) * cr + half) >> shift;
             const unsigned g3 = (((d2 >> 8) & 0xffu) * cb + ((d2 >> 16) & 0xffu) * cg + (d2 >> 24) * cr + half) >> shift;
             out = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+            // R == G == B for each of the four pixels?
+            const bool differs = ((d0 & 0xffu) != ((d0 >> 8) & 0xffu)) | (((d0 >> 8) & 0xffu) != ((d0 >> 16) & 0xffu)) |
+                                 ((d0 >> 24) != (d1 & 0xffu)) | ((d1 & 0xffu) != ((d1 >> 8) & 0xffu)) |
+                                 (((d1 >> 16) & 0xffu) != (d1 >> 24)) | ((d1 >> 24) != (d2 & 0xffu)) |
+                                 (((d2 >> 8) & 0xffu) != ((d2 >> 16) & 0xffu)) | (((d2 >> 16) & 0xffu) != (d2 >> 24));
+            if (differs) coloured = true;
         }
         *reinterpret_cast<unsigned*>(o + x0) = out;
-        return;
-    }
+    } else
     for (int i = 0; i < 4; i++) {
         const int x = x0 + i;
         if (x >= im.w) break;
         if (im.cn == 1) o[x] = s[x];
-        else o[x] = (uint8_t)((s[3 * x] * cb + s[3 * x + 1] * cg + s[3 * x + 2] * cr + half) >> shift);
+        else {
+            o[x] = (uint8_t)((s[3 * x] * cb + s[3 * x + 1] * cg + s[3 * x + 2] * cr + half) >> shift);
+            if (s[3 * x] != s[3 * x + 1] || s[3 * x + 1] != s[3 * x + 2]) coloured = true;
+        }
+    }
+    }
+    if (coloured && has_colour[b] == 0) has_colour[b] = 1;          // (a plain store: every writer writes 1)
+}
+
+// The channels of COLOURED 3-channel images as three planes (rgb + c * nb * slot, c = 0 .. 2, plane pitch): the input of the colour mode
+// of k_sobel_nms_rows.  Images whose channels are equal everywhere (has_colour == 0, k_grey) are skipped.  block (64,4), 4 pixels per thread.
+__global__ __launch_bounds__(256) void k_split_rgb(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ rgb, const int* __restrict__ has_colour,
+                                                   int gx, int gy)
+{
+    const TileId t = tile_of_block(gx, gy);
+    const int b = t.z;
+    const ImgDesc im = desc[b];
+    if (im.cn != 3 || has_colour[b] == 0) return;
+    const int x0 = (t.tx * 64 + threadIdx.x) * 4;
+    if (x0 >= im.w) return;
+    for (int y = t.ty * GREY_ROWS + threadIdx.y; y < imin((t.ty + 1) * GREY_ROWS, im.h); y += 4) {
+    const uint8_t* s = im.src + (size_t)y * im.sstride;
+    unsigned o[3] = {0u, 0u, 0u};
+    if (x0 + 3 < im.w) {
+        unsigned d0, d1, d2;                                          // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 (unaligned dword loads)
+        __builtin_memcpy(&d0, s + 3 * x0, 4); __builtin_memcpy(&d1, s + 3 * x0 + 4, 4); __builtin_memcpy(&d2, s + 3 * x0 + 8, 4);
+        o[0] = (d0 & 0xffu) | ((d0 >> 24) << 8) | (((d1 >> 16) & 0xffu) << 16) | (((d2 >> 8) & 0xffu) << 24);
+        o[1] = ((d0 >> 8) & 0xffu) | ((d1 & 0xffu) << 8) | ((d1 >> 24) << 16) | (((d2 >> 16) & 0xffu) << 24);
+        o[2] = ((d0 >> 16) & 0xffu) | (((d1 >> 8) & 0xffu) << 8) | ((d2 & 0xffu) << 16) | ((d2 >> 24) << 24);
+    } else {
+        for (int i = 0; i < 4 && x0 + i < im.w; i++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) o[c] |= (unsigned)s[3 * (x0 + i) + c] << (8 * i);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)                                       // (planes have a 64-byte pitch: whole dwords may be written)
+        *reinterpret_cast<unsigned*>(rgb + ((size_t)c * g.nb + b) * g.slot + rowoff(y, g.pitch) + x0) = o[c];
     }
 }
 

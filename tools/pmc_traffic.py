@@ -9,7 +9,7 @@ TCC block has 4 counter slots, FETCH_SIZE takes 3, WRITE_SIZE 2) of ONE device p
 Units and corrections as MI355X_MICROARCH.md (HBM section) prescribes: both counters report KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of wide coalesced streaming reads (x2), WRITE_SIZE is taken as is.  The stage's dispatches: k_grey,
 k_blur (or k_median3 + k_gauss357), k_median57, the main-Canny Sobel/NMS dispatch (the smaller of the two
-k_sobel_nms_rows grids, or k_sobel_nms_src) and the hysteresis launches that precede the HoughCircles Sobel/NMS dispatch.
+k_sobel_nms_rows<1 | 2 | 3> grids) and the hysteresis launches that precede the HoughCircles Sobel/NMS dispatch.
 The output records the hash of the kernel sources (bench.py refuses the figure when the kernels have changed since)."""
 import hashlib
 import json
