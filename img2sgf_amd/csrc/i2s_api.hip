@@ -520,10 +520,10 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         // -- kernel group 1 of i2s_last_kernel_timing
         const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
         if (fused0)
-            I2S_LAUNCH(1, (k_sobel_nms_rows<2>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
+            I2S_LAUNCH(1, (k_sobel_nms_rows<2, true>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
                                p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
         else if (rows_main)
-            I2S_LAUNCH(1, (k_sobel_nms_rows<1>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0,
+            I2S_LAUNCH(1, (k_sobel_nms_rows<1, true>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0,
                                p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
         if (has_c3) {
             // coloured images (d_colour): their channels as three planes in the slots of the blur bank that are still free (median3, gauss3,
@@ -532,7 +532,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             static_assert(I2S_PLANE_GAUSS3 == I2S_PLANE_MEDIAN3 + 1 && I2S_PLANE_MEDIAN5 == I2S_PLANE_MEDIAN3 + 2, "three consecutive scratch planes");
             uint8_t* rgb = plane_ptr(ctx, I2S_PLANE_MEDIAN3);
             I2S_LAUNCH(1, k_split_rgb, g_row, b64x4, ctx->d_desc, g, rgb, ctx->d_colour, rx, ry);
-            I2S_LAUNCH(1, (k_sobel_nms_rows<3>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, rgb, map0, edges, 0, p->canny_lo,
+            I2S_LAUNCH(1, (k_sobel_nms_rows<3, false>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, rgb, map0, edges, 0, p->canny_lo,
                        p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
         }
         // -- kernel group 2 of i2s_last_kernel_timing
@@ -574,7 +574,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipEventRecord(ctx->ev[1], st));
         // -- kernel group 6 of i2s_last_kernel_timing
         const int v_first = fused0 ? 1 : 0;
-        I2S_LAUNCH(6, (k_sobel_nms_rows<0>), dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, ctx->d_desc, g, grey, map0,
+        I2S_LAUNCH(6, (k_sobel_nms_rows<0, true>), dim3((unsigned)cgx * cgy * nb * (NVAR - v_first)), b256, ctx->d_desc, g, grey, map0,
                            (uint8_t*)nullptr, v_first, hc_lo, p->hc_param1, p->hc_param1, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, cgx, cgy);
         // -- kernel group 7 of i2s_last_kernel_timing
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);

@@ -48,15 +48,25 @@ __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned 
 // largest L1 magnitude, ties to the lower index (OpenCV canny.cpp, Appendix A.2 step 2) -- the Sobel part three times, everything
 // behind it once; images whose channels are equal everywhere (has_colour == 0) have been done in mode 1 / 2.
 // grid: ceil(w / 1024) x ceil(h / CR_R) x (nb * variants) workgroups of 4 wavefronts (4 consecutive 256-pixel column groups).
-template <int main_mode>
+//
+// BIN (round 4): planes whose pixels are all 0 or 255 in the band a wavefront walks -- the clean diagrams' grey plane and medians, every
+// edge image -- take the walk in BYTES first: with pixels as 0 / 1 the Sobel sums fit 4 bits (|dx|, |dy| <= 4 units of 255, magnitude <= 8),
+// so a lane's four pixels stay in one register from the load to the map byte (SWAR adds that cannot carry across bytes, compares through
+// bit 7, the sector limits as two 5-entry v_perm tables, selects as single v_bitop3).  The two-valued test runs on the rows as they are
+// loaded; a band that fails it is walked again by the 16-bit code below, which overwrites whatever the byte walk had stored.
+template <int main_mode, bool BIN>
 __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
                                                         uint8_t* __restrict__ maps, uint8_t* __restrict__ edges, int v_first, int low,
                                                         int high, int high_main, int* __restrict__ weak,
                                                         int* __restrict__ weak_main, const int* __restrict__ has_colour, int gx, int gy)
 {
     const TileId tl = tile_of_block(gx, gy);
-    const int b = tl.z % g.nb;
-    const int v = main_mode ? 0 : v_first + tl.z / g.nb;
+    // image-major: every XCD's contiguous share of the grid (tile_of_block) then holds whole images with all their planes -- with the
+    // planes outermost an XCD got one KIND of plane, and the byte walk's gain on the two-valued ones was hidden behind the XCDs
+    // that held Gaussian planes (7.3 us per diagram either way; profiles/r04_c_canny_bin.txt)
+    const int nv = main_mode ? 1 : NVAR - v_first;
+    const int b = tl.z / nv;
+    const int v = main_mode ? 0 : v_first + tl.z % nv;
     constexpr int NC = main_mode == 3 ? 3 : 1;                     // channels whose gradients compete
     const ImgDesc im = desc[b];
     // the main Canny of an image runs here, on its grey plane, unless the image really is coloured (k_grey's has_colour: see there)
@@ -142,6 +152,141 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     unsigned wk_acc = 0, wk0_acc = 0;
     static_assert((CR_R + 4) % 6 == 0, "the row loop is unrolled by the ring depths (3 and 2)");
     const int t_end = imin(CR_R + 4, h + 2 - (y0 - 2));               // input rows beyond h + 1 feed no output of this band
+    if constexpr (BIN && NC == 1) {
+        #ifdef I2S_EXP_NOBIN
+        const bool gauss_plane = true;                                 // experiment builds only (tools: -DI2S_EXP_NOBIN)
+#else
+        const bool gauss_plane = main_mode == 0 && v >= 3 && (v & 1);  // never two-valued (short of a constant image): not tried
+#endif  // never two-valued (short of a constant image): not tried
+        if (!gauss_plane) {
+            constexpr unsigned ONES = 0x01010101u, TOP = 0x80808080u, FOUR = 0x04040404u;
+            // thresholds in units of 255: magnitude m (units) passes  255 m > thr  <=>  m >= floor(thr / 255) + 1
+            const unsigned tlb = (unsigned)(low < 0 ? 0 : imin(low / 255 + 1, 100)) * ONES;
+            const unsigned thb = (unsigned)(high < 0 ? 0 : imin(high / 255 + 1, 100)) * ONES;
+            const unsigned th0b = (unsigned)(high_main < 0 ? 0 : imin(high_main / 255 + 1, 100)) * ONES;
+            unsigned ve = 0;                                            // pixels of the end-lane dword that exist (the two-valued test looks at them too)
+            if (has_e) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (lane == 0 || x0 + 4 + q < w) ve |= 0xffu << (8 * q);
+            }
+            const unsigned vmt = active ? vm : 0u;
+            unsigned HD[3], RS[3], BE[3];     // of the last 3 input rows: right - left + 1, left + 2 centre + right, the end-lane bytes
+            unsigned MG[3], SLb[3], SRb[3];   // magnitudes of the last 3 gradient rows: own pixels, shifted by one pixel to either side
+            unsigned S22[2], S67[2], SGf[2];  // of the last 2 gradient rows, in bit 7 of each byte: the two axis sectors, "signs differ"
+#pragma unroll
+            for (int i = 0; i < 3; i++) HD[i] = RS[i] = BE[i] = MG[i] = SLb[i] = SRb[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 2; i++) S22[i] = S67[i] = SGf[i] = 0;
+            unsigned odd = 0;
+            bool two_valued = true;
+            for (int t0 = 0; t0 < t_end; t0 += 6) {
+                if (__any((odd & 0x7f7f7f7fu) != 0u ? 1 : 0)) { two_valued = false; break; }
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int t = t0 + u;
+                    const int yi = y0 - 2 + t;
+                    const unsigned M = nM[0], E = nE[0];
+                    {
+                        const int ro = rowoff(iclamp(yi + 1, 0, h - 1), sp);
+                        nM[0] = bl_bload(pbuf[0], ro, xm); nE[0] = bl_bload(pbuf[0], ro, xeo);
+                    }
+                    odd |= (((M >> 1) ^ M) & vmt) | (((E >> 1) ^ E) & ve);      // (& 0x7f7f7f7f at the test)
+                    const int ps = u % 3;
+                    unsigned L = bl_from_prev_lane(M, E), R = bl_from_next_lane(M, E), Mf = M;
+                    if (fix) {
+                        BL_KEEP_BRANCH();
+                        const unsigned l2 = __builtin_amdgcn_perm(M, L, sL), m2 = __builtin_amdgcn_perm(M, L, sM), r2 = __builtin_amdgcn_perm(R, M, sR);
+                        L = l2; Mf = m2; R = r2;
+                    }
+                    BE[ps] = __builtin_amdgcn_perm(e_hi ? R : Mf, e_hi ? Mf : L, eS) & 0x00010101u;
+                    {
+                        const unsigned bl = L & ONES, bm = Mf & ONES, br = R & ONES;
+                        const unsigned lf = alignbyte(bm, bl, 3), rt = alignbyte(br, bm, 1);       // pixels x - 1 and x + 1 of the lane's four
+                        RS[ps] = lf + rt + bm + bm;                    // (v_lshlrev is a half-rate instruction, v_add is not)
+                        HD[ps] = rt + ONES - lf;
+                    }
+                    const int yg = yi - 1;
+                    const int gs = u % 3, g2 = u % 2;
+                    if (t >= 2) {
+                        const int top = (u + 1) % 3, mid = (u + 2) % 3, bot = ps;
+                        const unsigned inm = (yg >= 0 && yg < h) ? vm : 0u;             // pixels whose gradient exists
+                        // dx + 4 and dy + 4 (0 .. 8); zero gradients outside the image
+                        const unsigned dxb = bitop3<0xCA>(inm, HD[top] + HD[mid] + HD[mid] + HD[bot], FOUR);
+                        const unsigned dyb = bitop3<0xCA>(inm, RS[bot] + FOUR - RS[top], FOUR);
+                        // |d| = |i - 4| as a table of i & 7 (i = 8 and i = 0 share an entry: both are 4)
+                        const unsigned ax = __builtin_amdgcn_perm(0x03020100u, 0x01020304u, dxb & 0x07070707u);
+                        const unsigned ay = __builtin_amdgcn_perm(0x03020100u, 0x01020304u, dyb & 0x07070707u);
+                        const unsigned mag = ax + ay;
+                        SGf[g2] = ((dxb | TOP) - FOUR) ^ ((dyb | TOP) - FOUR);          // bit 7 of (d + 4 | 0x80) - 4: d >= 0 (0 counts as positive: OpenCV's (dx ^ dy) < 0)
+                        // |dy| 2^15 < |dx| 13573  <=>  |dy| < (0, 1, 1, 2, 2)[|dx|];  |dy| 2^15 > |dx| 79109  <=>  |dy| >= (1, 3, -, -, -)[|dx|]
+                        const unsigned t22 = __builtin_amdgcn_perm(0x00000002u, 0x02010100u, ax);
+                        const unsigned t67 = __builtin_amdgcn_perm(0x00000009u, 0x09090301u, ax);
+                        const unsigned ayh = ay | TOP;
+                        S22[g2] = ~(ayh - t22); S67[g2] = ayh - t67;
+                        // end lanes: bytes (xe - 1, xe, xe + 1) of the three rows are 0 / 1, signed dot products do
+                        const unsigned et = BE[top], em = BE[mid], eb = BE[bot];
+                        const int edx = __builtin_amdgcn_sdot4((int)et, 0x000100ff, __builtin_amdgcn_sdot4((int)em, 0x000200fe, __builtin_amdgcn_sdot4((int)eb, 0x000100ff, 0, false), false), false);
+                        const int edy = __builtin_amdgcn_sdot4((int)eb, 0x00010201, __builtin_amdgcn_sdot4((int)et, 0x00fffeff, 0, false), false);
+                        const unsigned mge = (e_ok && yg >= 0 && yg < h) ? (unsigned)(iabs_(edx) + iabs_(edy)) : 0u;
+                        MG[gs] = mag;
+                        const unsigned ml = bl_from_prev_lane(mag, mge << 24), mr = bl_from_next_lane(mag, mge);
+                        SLb[gs] = alignbyte(mag, ml, 3);
+                        SRb[gs] = alignbyte(mr, mag, 1);
+                    }
+                    const int yn = yi - 2;
+                    unsigned outw = ONES, outw0 = ONES;
+                    const bool emit = t >= 4 && yn < h;
+                    if (emit) {
+                        const int ra = (u + 1) % 3, rc = (u + 2) % 3, rb = gs, gq = g2 ^ 1;
+                        const unsigned curh = MG[rc] | TOP;
+                        const unsigned ktl = curh - tlb;
+                        if (__any((ktl & TOP) != 0u ? 1 : 0)) {
+                            // every comparison leaves its answer in bit 7 of the byte ((a | 0x80) - b: a >= b), and the sector decides which pair counts:
+                            // no byte masks, no selects.  OpenCV keeps m > first && m >= second on the axes, m > both on a diagonal.
+                            const unsigned cur1 = curh - ONES;                                   // (.. - b): a > b
+                            const unsigned kh = bitop3<0x80>(S22[gq], cur1 - SLb[rc], curh - SRb[rc]);
+                            const unsigned kv = bitop3<0x80>(S67[gq], cur1 - MG[ra], curh - MG[rb]);
+                            const unsigned kd = bitop3<0xCA>(SGf[gq], (cur1 - SRb[ra]) & (cur1 - SLb[rb]), (cur1 - SLb[ra]) & (cur1 - SRb[rb]));
+                            const unsigned k7 = bitop3<0xFE>(kh, kv, bitop3<0x02>(S22[gq], S67[gq], kd)) & ktl;       // bit 7: kept
+                            outw = (((k7 ^ TOP) >> 7) & ONES) | (((k7 & (curh - thb)) >> 6) & 0x02020202u);
+                            if (main_mode == 2) outw0 = (((k7 ^ TOP) >> 7) & ONES) | (((k7 & (curh - th0b)) >> 6) & 0x02020202u);
+                        }
+                        outw = (outw & vm) | (ONES & ~vm);
+                        wk_acc |= (outw - ONES) & ~outw & TOP;
+                        if (main_mode == 2) {
+                            outw0 = (outw0 & vm) | (ONES & ~vm);
+                            wk0_acc |= (outw0 - ONES) & ~outw0 & TOP;
+                        }
+                    }
+                    BL_SCHED_FENCE();
+                    BL_CONSUME(nM[0], nE[0]);
+                    BL_SCHED_FENCE();
+                    if (emit && active) {
+                        const int off = rowoff(yn, g.pitch);
+                        bl_bstore(mbuf, off, xm, outw);
+                        if (mp0) bl_bstore(m0buf, off, xm, outw0);
+                        if (ep) { const unsigned outm = mp0 ? outw0 : outw; bl_bstore(ebuf, off, xm, ((outm >> 1) & ONES) * 0xffu); }
+                    }
+                }
+            }
+            if (two_valued && __any((odd & 0x7f7f7f7fu) != 0u ? 1 : 0)) two_valued = false;
+            if (two_valued) {
+                // the band is one row of 64 x 32 hysteresis tiles: one key per tile (16 lanes) that holds a weak pixel
+                const unsigned long long bw = __ballot(wk_acc != 0u && active), bw0 = __ballot(mp0 != nullptr && wk0_acc != 0u && active);
+                if ((lane & 15) == 0) {
+                    const int tile_x = cgp * 4 + (lane >> 4), tile_y = y0 / CT_H;
+                    const unsigned long long grp = 0xffffull << lane;
+                    int* weak_first = main_mode == 1 ? weak_main : weak;
+                    if (bw & grp) weak_first[1 + atomicAdd(&weak_first[0], 1)] = (int)(((size_t)m_first * g.nb + b) * g.tiles + (size_t)tile_y * g.tw + tile_x);
+                    if (bw0 & grp) weak_main[1 + atomicAdd(&weak_main[0], 1)] = (int)((size_t)b * g.tiles + (size_t)tile_y * g.tw + tile_x);
+                }
+                return;
+            }
+            wk_acc = 0; wk0_acc = 0;
+            const int ro = rowoff(iclamp(y0 - 2, 0, h - 1), sp);
+            nM[0] = bl_bload(pbuf[0], ro, xm); nE[0] = bl_bload(pbuf[0], ro, xeo);
+        }
+    }
     for (int t0 = 0; t0 < t_end; t0 += 6) {
 #pragma unroll
         for (int u = 0; u < 6; u++) {

@@ -160,6 +160,12 @@ static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
     return c;
 }
+// v_dot4_i32_i8: the same with signed bytes
+static inline int __builtin_amdgcn_sdot4(int a, int b, int c, bool)
+{
+    for (int i = 0; i < 4; i++) c += (int)(signed char)((unsigned)a >> (8 * i)) * (int)(signed char)((unsigned)b >> (8 * i));
+    return c;
+}
 static inline int __mul24(int a, int b) { return a * b; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }

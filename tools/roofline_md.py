@@ -24,7 +24,7 @@ def passes(path):
         k, full, d = base(r["kernel"]), r["kernel"], float(r["duration_us"])
         if cur is None:
             cur, hc_seen = {}, False
-        if k == "k_sobel_nms_rows" and "<0>" in full:
+        if k == "k_sobel_nms_rows" and "<0" in full:
             hc_seen = True
             g = "k_sobel_nms_rows(HoughCircles x7)"
         elif k in ("k_sobel_nms_rows", "k_sobel_nms_src"):
