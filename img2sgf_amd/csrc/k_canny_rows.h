@@ -58,7 +58,8 @@ template <int main_mode, bool BIN>
 __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restrict__ desc, Geo g, const uint8_t* __restrict__ planes,
                                                         uint8_t* __restrict__ maps, uint8_t* __restrict__ edges, int v_first, int low,
                                                         int high, int high_main, int* __restrict__ weak,
-                                                        int* __restrict__ weak_main, const int* __restrict__ has_colour, int gx, int gy)
+                                                        int* __restrict__ weak_main, const int* __restrict__ has_colour,
+                                                        const int* __restrict__ band_flags, int gx, int gy)
 {
     const TileId tl = tile_of_block(gx, gy);
     // image-major: every XCD's contiguous share of the grid (tile_of_block) then holds whole images with all their planes -- with the
@@ -154,22 +155,28 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     const int t_end = imin(CR_R + 4, h + 2 - (y0 - 2));               // input rows beyond h + 1 feed no output of this band
     if constexpr (BIN && NC == 1) {
         #ifdef I2S_EXP_NOBIN
-        const bool gauss_plane = true;                                 // experiment builds only (tools: -DI2S_EXP_NOBIN)
+        bool try_bytes = false;                                        // experiment builds only (-DI2S_EXP_NOBIN)
 #else
-        const bool gauss_plane = main_mode == 0 && v >= 3 && (v & 1);  // never two-valued (short of a constant image): not tried
-#endif  // never two-valued (short of a constant image): not tried
-        if (!gauss_plane) {
+        // not tried: Gaussian planes (never two-valued, short of a constant image); the grey plane and the medians of a band k_blur has
+        // flagged (band_flags: the HoughCircles dispatch runs behind k_blur; the main Canny runs before it and has only the next test);
+        // bands whose first row already fails
+        bool try_bytes = !(main_mode == 0 && v >= 3 && (v & 1));
+        if (try_bytes && main_mode == 0 && v != 1 && band_flags != nullptr)
+            try_bytes = band_flags[((size_t)b * mb_bands_y(g.hmax) + (y0 / MB_R)) * mb_bands_x(g.wmax) + cgp] == 0;
+#endif
+        unsigned ve = 0;                                                // pixels of the end-lane dword that exist (the two-valued test looks at them too)
+        if (has_e) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (lane == 0 || x0 + 4 + q < w) ve |= 0xffu << (8 * q);
+        }
+        const unsigned vmt = active ? vm : 0u;
+        if (try_bytes && __any(((((nM[0] >> 1) ^ nM[0]) & vmt) | (((nE[0] >> 1) ^ nE[0]) & ve)) & 0x7f7f7f7fu ? 1 : 0)) try_bytes = false;
+        if (try_bytes) {
             constexpr unsigned ONES = 0x01010101u, TOP = 0x80808080u, FOUR = 0x04040404u;
             // thresholds in units of 255: magnitude m (units) passes  255 m > thr  <=>  m >= floor(thr / 255) + 1
             const unsigned tlb = (unsigned)(low < 0 ? 0 : imin(low / 255 + 1, 100)) * ONES;
             const unsigned thb = (unsigned)(high < 0 ? 0 : imin(high / 255 + 1, 100)) * ONES;
             const unsigned th0b = (unsigned)(high_main < 0 ? 0 : imin(high_main / 255 + 1, 100)) * ONES;
-            unsigned ve = 0;                                            // pixels of the end-lane dword that exist (the two-valued test looks at them too)
-            if (has_e) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) if (lane == 0 || x0 + 4 + q < w) ve |= 0xffu << (8 * q);
-            }
-            const unsigned vmt = active ? vm : 0u;
             unsigned HD[3], RS[3], BE[3];     // of the last 3 input rows: right - left + 1, left + 2 centre + right, the end-lane bytes
             unsigned MG[3], SLb[3], SRb[3];   // magnitudes of the last 3 gradient rows: own pixels, shifted by one pixel to either side
             unsigned S22[2], S67[2], SGf[2];  // of the last 2 gradient rows, in bit 7 of each byte: the two axis sectors, "signs differ"
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                 return;
             }
             wk_acc = 0; wk0_acc = 0;
-            const int ro = rowoff(iclamp(y0 - 2, 0, h - 1), sp);
+            const int ro = rowoff(iclamp(y0 - 2, 0, h - 1), sp);       // start over (the 16-bit walk below)
             nM[0] = bl_bload(pbuf[0], ro, xm); nE[0] = bl_bload(pbuf[0], ro, xeo);
         }
     }
