@@ -16,30 +16,34 @@ namespace i2s {
 
 constexpr int CR_R = CT_H;       // output rows per wavefront = one row of hysteresis tiles (+4 apron rows of input; 4 x CT_H measured: no faster)
 
-struct CrThr { unsigned lowp, highp, high0p; };
+struct CrThr { unsigned lowp1, highp1, high0p1; };      // thresholds + 1, twice (16-bit halves): m > thr  <=>  m >= thr + 1
 
-// suppression of one pixel pair (two 16-bit lanes): cur = magnitudes, L / R / above / below and the four diagonals, ax / ay the
-// absolute gradients, msk = 0xffff where the gradient signs differ.  Returns the map values (0 / 1 / 2 per 16-bit lane) for the
+// suppression of one pixel pair (two 16-bit halves): cur = magnitudes, L / R / above / below and the four diagonals, ax / ay the
+// absolute gradients, sgf = bit 15 set where the gradient signs differ.  Returns the map values (0 / 1 / 2 per half) for the
 // thresholds (low, high) and -- TWO -- (low, high0).
+// Every comparison is (a | 0x8000) - b in ONE 32-bit subtraction (a full-rate instruction, the packed 16-bit forms are not): all values
+// are below 2^15, so no borrow crosses the halves and bit 15 of each half says a >= b.  The answers stay in bit 15: the sector picks its
+// pair of neighbours by v_bitop3 -- horizontal (left, right), vertical (above, below), diagonal by the gradient signs: signs differ ->
+// (above right, below left), else (above left, below right).  OpenCV keeps m > first && m >= second on the axes, m > both on a diagonal.
 template <bool TWO>
 __device__ __forceinline__ void cr_nms_pair(unsigned cur, unsigned l1, unsigned r1, unsigned c0, unsigned c2, unsigned l0, unsigned r0,
-                                            unsigned l2, unsigned r2, unsigned axp, unsigned ay, unsigned msk, const CrThr& th, unsigned& o, unsigned& om)
+                                            unsigned l2, unsigned r2, unsigned axp, unsigned ay, unsigned sgf, const CrThr& th, unsigned& o, unsigned& om)
 {
-    // The two neighbours of the pixel's sector are selected first and compared once: horizontal (left, right), vertical
-    // (above, below), diagonal by the gradient signs -- signs differ -> (above right, below left), else (above left, below
-    // right).  OpenCV keeps cur > first && cur >= second on the axes and cur > both on a diagonal; cur > d  <=>  cur >= d + 1.
-    const unsigned d1 = bsel(msk, r0, l0), d2 = pk_bits(pk_from(bsel(msk, l2, r2)) + (short)1);
+    constexpr unsigned H = 0x80008000u, ONE = 0x00010001u;
     const v2u ax = pku_from(axp);
     // |dy| 2^15 < |dx| 13573  <=>  |dy| <= q,  |dy| 2^15 > |dx| 79109  <=>  |dy| > 2 |dx| + q,  q = floor(|dx| 13573 / 2^15) = (|dx| 53 + (|dx| 5 >> 8)) >> 7:
     // 13573 = 53 * 256 + 5 is odd, so the quotient is never exact for |dx| > 0, and for |dx| = |dy| = 0 the magnitude is 0 and nothing is kept
-    const v2u q = (ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7;
-    const unsigned s22 = ~pk_gt(ay, pku_bits(q));
-    const unsigned s67 = pk_gt(ay, pku_bits(ax + ax + q));
-    const unsigned n1 = bsel(s22, l1, bsel(s67, c0, d1)), n2 = bsel(s22, r1, bsel(s67, c2, d2));
-    const unsigned keep = pk_gt(cur, n1) & ~pk_gt(n2, cur);
-    const unsigned kept = keep & pk_gt(cur, th.lowp);
-    o = (kept & pk_gt(cur, th.highp) & 0x00020002u) | (~kept & 0x00010001u);
-    if (TWO) om = (kept & pk_gt(cur, th.high0p) & 0x00020002u) | (~kept & 0x00010001u);
+    const unsigned q = pku_bits((ax * (unsigned short)53 + ((ax * (unsigned short)5) >> 8)) >> 7);
+    const unsigned s22 = (q | H) - ay;
+    const unsigned s67 = (ay | H) - (axp + axp + q + ONE);
+    const unsigned curh = cur | H, cur1 = curh - ONE;                  // (cur1 - b): cur > b
+    const unsigned kh = bitop3<0x80>(s22, cur1 - l1, curh - r1);
+    const unsigned kv = bitop3<0x80>(s67, cur1 - c0, curh - c2);
+    const unsigned kd = bitop3<0xCA>(sgf, (cur1 - r0) & (cur1 - l2), (cur1 - l0) & (cur1 - r2));
+    const unsigned k = bitop3<0xFE>(kh, kv, bitop3<0x02>(s22, s67, kd)) & (curh - th.lowp1);
+    const unsigned nk = ((k ^ H) >> 15) & ONE;
+    o = nk | (((k & (curh - th.highp1)) >> 14) & 0x00020002u);
+    if (TWO) om = nk | (((k & (curh - th.high0p1)) >> 14) & 0x00020002u);
 }
 
 // main_mode: 0 = HoughCircles' Canny of variants v_first .. (plane v -> map 1 + v), 1 = main Canny of grey
@@ -94,9 +98,9 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     for (int c = 0; c < NC; c++) pbuf[c] = bl_buf(plane + (size_t)c * g.nb * g.slot);
     const BlBuf mbuf = bl_buf(mp), m0buf = bl_buf(mp0 ? mp0 : mp), ebuf = bl_buf(ep ? ep : mp);
     CrThr th;
-    th.lowp = (unsigned)(iclamp(low, -1, 4095) & 0xffff) * 0x00010001u;
-    th.highp = (unsigned)(iclamp(high, -1, 4095) & 0xffff) * 0x00010001u;
-    th.high0p = (unsigned)(iclamp(high_main, -1, 4095) & 0xffff) * 0x00010001u;
+    th.lowp1 = (unsigned)(iclamp(low, -1, 4095) + 1) * 0x00010001u;
+    th.highp1 = (unsigned)(iclamp(high, -1, 4095) + 1) * 0x00010001u;
+    th.high0p1 = (unsigned)(iclamp(high_main, -1, 4095) + 1) * 0x00010001u;
 
     // BORDER_REPLICATE along x: byte k of the (L, M, R) triple is pixel x0 - 4 + k; lanes whose 3 x 4 bytes reach outside the
     // image rebuild the triple with byte permutes (selectors computed once)
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     // magnitudes of the last 3 gradient rows: the own pairs (pixels 0,1 and 2,3) and the same row shifted by one pixel --
     // (-1,0), (1,2), (3,4), formed ONCE per row from the neighbour lanes' pairs (each row is used by three suppressions)
     unsigned M01[3], M23[3], SL[3], SM[3], SR[3];
-    // of the last 2 gradient rows: |dx|, |dy| and the mask "signs differ" (the suppression needs nothing else of the gradients)
+    // of the last 2 gradient rows: |dx|, |dy| and (bit 15) "signs differ" (the suppression needs nothing else of the gradients)
     unsigned AX01[2], AX23[2], AY01[2], AY23[2], SG01[2], SG23[2];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                     const unsigned ax01 = pk_bits(pk_abs(pk_from(dx01))), ay01 = pk_bits(pk_abs(pk_from(dy01)));
                     const unsigned ax23 = pk_bits(pk_abs(pk_from(dx23))), ay23 = pk_bits(pk_abs(pk_from(dy23)));
                     AX01[g2] = ax01; AX23[g2] = ax23; AY01[g2] = ay01; AY23[g2] = ay23;
-                    SG01[g2] = pk_bits(pk_from(dx01 ^ dy01) >> 15); SG23[g2] = pk_bits(pk_from(dx23 ^ dy23) >> 15);
+                    SG01[g2] = dx01 ^ dy01; SG23[g2] = dx23 ^ dy23;               // bit 15 of each half: the signs differ
                 }
                 M01[gs] = mg01; M23[gs] = mg23;
                 // pair (x0 - 2, x0 - 1) of the left neighbour and pair (x0 + 4, x0 + 5) of the right one (only their inner halves are used)
