@@ -190,16 +190,25 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
             for (int i = 0; i < 2; i++) S22[i] = S67[i] = SGf[i] = 0;
             unsigned odd = 0;
             bool two_valued = true;
+            // the byte walk spends too few cycles on a row for ONE row of loads in flight to cover the memory latency: three rows ahead,
+            // a statically indexed ring; every store on every path (BL_NO_STORE) so that the compiler's vmcnt counts what is really pending
+            unsigned rM[3], rE[3];
+            rM[0] = nM[0]; rE[0] = nE[0];
+#pragma unroll
+            for (int i = 1; i < 3; i++) {
+                const int ro = rowoff(iclamp(y0 - 2 + i, 0, h - 1), sp);
+                rM[i] = bl_bload(pbuf[0], ro, xm); rE[i] = bl_bload(pbuf[0], ro, xeo);
+            }
             for (int t0 = 0; t0 < t_end; t0 += 6) {
                 if (__any((odd & 0x7f7f7f7fu) != 0u ? 1 : 0)) { two_valued = false; break; }
 #pragma unroll
                 for (int u = 0; u < 6; u++) {
                     const int t = t0 + u;
                     const int yi = y0 - 2 + t;
-                    const unsigned M = nM[0], E = nE[0];
+                    const unsigned M = rM[u % 3], E = rE[u % 3];
                     {
-                        const int ro = rowoff(iclamp(yi + 1, 0, h - 1), sp);
-                        nM[0] = bl_bload(pbuf[0], ro, xm); nE[0] = bl_bload(pbuf[0], ro, xeo);
+                        const int ro = rowoff(iclamp(yi + 3, 0, h - 1), sp);
+                        rM[u % 3] = bl_bload(pbuf[0], ro, xm); rE[u % 3] = bl_bload(pbuf[0], ro, xeo);
                     }
                     odd |= (((M >> 1) ^ M) & vmt) | (((E >> 1) ^ E) & ve);      // (& 0x7f7f7f7f at the test)
                     const int ps = u % 3;
@@ -269,14 +278,12 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
                             wk0_acc |= (outw0 - ONES) & ~outw0 & TOP;
                         }
                     }
-                    BL_SCHED_FENCE();
-                    BL_CONSUME(nM[0], nE[0]);
-                    BL_SCHED_FENCE();
-                    if (emit && active) {
-                        const int off = rowoff(yn, g.pitch);
-                        bl_bstore(mbuf, off, xm, outw);
-                        if (mp0) bl_bstore(m0buf, off, xm, outw0);
-                        if (ep) { const unsigned outm = mp0 ? outw0 : outw; bl_bstore(ebuf, off, xm, ((outm >> 1) & ONES) * 0xffu); }
+                    {
+                        const int off = rowoff(emit ? yn : 0, g.pitch);
+                        const unsigned xs = (emit && active) ? xm : BL_NO_STORE;
+                        bl_bstore(mbuf, off, xs, outw);
+                        if (main_mode == 2) bl_bstore(m0buf, off, mp0 ? xs : BL_NO_STORE, outw0);
+                        if (main_mode != 0) { const unsigned outm = mp0 ? outw0 : outw; bl_bstore(ebuf, off, ep ? xs : BL_NO_STORE, ((outm >> 1) & ONES) * 0xffu); }
                     }
                 }
             }
