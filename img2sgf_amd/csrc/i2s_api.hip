@@ -506,7 +506,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
 
         I2S_HIP(hipEventRecord(ctx->ev[0], st));
         // -- kernel group 0 of i2s_last_kernel_timing
-        if (need_grey) I2S_LAUNCH(0, k_grey, g_row, b64x4, ctx->d_desc, g, grey, p->grey_shift, ctx->d_colour, rx, ry);
+        if (need_grey) I2S_LAUNCH(0, k_grey, g_row, b64x4, ctx->d_desc, g, grey, p->grey_shift, ctx->d_colour, ctx->d_mflags, rx, ry);
         // Order of the two independent halves of the blur+Canny stage (round 4): the main Canny FIRST.  It is bound by its arithmetic and
         // does not care where the grey source comes from; k_blur is bound by its six plane stores, and those stream ~15 % faster when
         // the source it reads at the same time is already in the Infinity Cache than when HBM has to turn around between reads and
@@ -521,10 +521,10 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         const int cgx = cdiv(wmax, 1024), cgy = cdiv(hmax, CR_R);      // k_sobel_nms_rows: 4 wavefronts x 256 pixels, CR_R rows
         if (fused0)
             I2S_LAUNCH(1, (k_sobel_nms_rows<2, true>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0, hc_lo,
-                               p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, (const int*)nullptr, cgx, cgy);
+                               p->hc_param1, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, (const int*)ctx->d_mflags, cgx, cgy);
         else if (rows_main)
             I2S_LAUNCH(1, (k_sobel_nms_rows<1, true>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, grey, map0, edges, 0,
-                               p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, (const int*)nullptr, cgx, cgy);
+                               p->canny_lo, p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, (const int*)ctx->d_mflags, cgx, cgy);
         if (has_c3) {
             // coloured images (d_colour): their channels as three planes in the slots of the blur bank that are still free (median3, gauss3,
             // median5: consecutive), then the row kernel's colour mode (round 1's LDS-tile kernel took 680 us for the reference's nine colour
@@ -533,7 +533,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             uint8_t* rgb = plane_ptr(ctx, I2S_PLANE_MEDIAN3);
             I2S_LAUNCH(1, k_split_rgb, g_row, b64x4, ctx->d_desc, g, rgb, ctx->d_colour, rx, ry);
             I2S_LAUNCH(1, (k_sobel_nms_rows<3, false>), dim3((unsigned)cgx * cgy * nb), b256, ctx->d_desc, g, rgb, map0, edges, 0, p->canny_lo,
-                       p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, (const int*)nullptr, cgx, cgy);
+                       p->canny_hi, p->canny_hi, worklist(ctx, 1), worklist(ctx, 0), ctx->d_colour, (const int*)ctx->d_mflags, cgx, cgy);
         }
         // -- kernel group 2 of i2s_last_kernel_timing
         rc = run_hysteresis(ctx, 0, fx * fy * nb);

@@ -14,6 +14,12 @@ namespace i2s {
 constexpr int FT_W = 64;   // filter output tile
 constexpr int FT_H = 32;
 
+constexpr int BL_R = 64;          // output rows per wavefront (+6 apron rows of horizontal work)
+// bands of the two-valued speculation (k_blur; k_median57_bin for the integer-kernel path): a flag per 256 x 64 band
+constexpr int MB_R = BL_R;        // output rows per wavefront (+6 apron rows); a band = 256 x MB_R pixels
+__device__ __host__ inline int mb_bands_x(int wmax) { return (wmax + 255) / 256; }
+__device__ __host__ inline int mb_bands_y(int hmax) { return (hmax + MB_R - 1) / MB_R; }
+
 // ---- K1: grey plane.  cn==1: copy; cn==3: (ch0*B + ch1*G + ch2*R + half) >> shift, where the
 // reference hands RGB data to COLOR_BGR2GRAY, so ch0 (=R) is weighted as "blue" (img2sgf.py:153).
 // block (64,4), each thread 4 pixels of GREY_ROWS / 4 rows (a workgroup of 256 x 4 pixels, as in rounds 1-3, is 450 000 workgroups for a
@@ -23,8 +29,11 @@ constexpr int GREY_ROWS = 32;
 // over as RGB (Image.open(...).convert("RGB"), img2sgf.py:651), also the greyscale scans that are most of its inputs: with R = G = B the
 // grey value is that value under either set of weights and the 3-channel Canny picks channel 0 of three identical gradients, so such an
 // image goes through the single-channel kernels (k_sobel_nms_rows on its grey plane) bit for bit.
+// band_flags (zeroed by the host; the flags of k_blur's two-valued speculation, see there): raised for the 256 x BL_R band of this workgroup
+// when a grey value other than 0 / 255 comes by -- scans are 97 % such bands, and neither k_blur nor the main Canny then starts a
+// speculative walk that its first rows would stop.
 __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, Geo g, uint8_t* __restrict__ grey, int shift, int* __restrict__ has_colour,
-                                              int gx, int gy)
+                                              int* __restrict__ band_flags, int gx, int gy)
 {
     const TileId t = tile_of_block(gx, gy);
     const int b = t.z;
@@ -36,6 +45,7 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
     if (shift == 14) { cb = 1868; cg = 9617; cr = 4899; } else { cb = 3735; cg = 19235; cr = 9798; }
     const int half = 1 << (shift - 1);
     bool coloured = false;
+    unsigned odd = 0;                                                // bits 0 .. 6 of a byte: the pixel is neither 0 nor 255
     for (int y = t.ty * GREY_ROWS + threadIdx.y; y < imin((t.ty + 1) * GREY_ROWS, im.h); y += 4) {
     const uint8_t* s = im.src + (size_t)y * im.sstride;
     uint8_t* o = grey + (size_t)b * g.slot + rowoff(y, g.pitch);
@@ -59,6 +69,7 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
             if (differs) coloured = true;
         }
         *reinterpret_cast<unsigned*>(o + x0) = out;
+        odd |= (out >> 1) ^ out;
     } else
     for (int i = 0; i < 4; i++) {
         const int x = x0 + i;
@@ -68,9 +79,15 @@ __global__ __launch_bounds__(256) void k_grey(const ImgDesc* __restrict__ desc, 
             o[x] = (uint8_t)((s[3 * x] * cb + s[3 * x + 1] * cg + s[3 * x + 2] * cr + half) >> shift);
             if (s[3 * x] != s[3 * x + 1] || s[3 * x + 1] != s[3 * x + 2]) coloured = true;
         }
+        odd |= ((unsigned)o[x] >> 1) ^ o[x];
     }
     }
     if (coloured && has_colour[b] == 0) has_colour[b] = 1;          // (a plain store: every writer writes 1)
+    if ((odd & 0x7f7f7f7fu) != 0u && band_flags != nullptr) {
+        static_assert(BL_R % GREY_ROWS == 0, "a k_grey workgroup lies inside one band");
+        int* f = band_flags + ((size_t)b * mb_bands_y(g.hmax) + t.ty * GREY_ROWS / BL_R) * mb_bands_x(g.wmax) + t.tx;
+        if (*f == 0) *f = 1;
+    }
 }
 
 // The channels of COLOURED 3-channel images as three planes (rgb + c * nb * slot, c = 0 .. 2, plane pitch): the input of the colour mode
@@ -196,11 +213,6 @@ __global__ __launch_bounds__(256) void k_gauss357(const ImgDesc* __restrict__ de
 // Top / bottom: the Gaussians read row reflect101(y); the median ring repeats the first / last image row.
 // Host side: used when every tap set sums to 256 (always for OpenCV's bit-exact kernels; the plain-rounding compatibility
 // mode can give 257, for which the integer kernels below remain).
-constexpr int BL_R = 64;          // output rows per wavefront (+6 apron rows of horizontal work)
-// bands of the two-valued speculation (k_blur; k_median57_bin for the integer-kernel path): a flag per 256 x 64 band
-constexpr int MB_R = BL_R;        // output rows per wavefront (+6 apron rows); a band = 256 x MB_R pixels
-__device__ __host__ inline int mb_bands_x(int wmax) { return (wmax + 255) / 256; }
-__device__ __host__ inline int mb_bands_y(int hmax) { return (hmax + MB_R - 1) / MB_R; }
 struct BlurTaps { float c3, a3, c5, a5, b5, c7, a7, b7, d7; };   // centre, +-1, +-2, +-3 of the 3 / 5 / 7-tap kernels
 #define bl_f(v, byte) bl_fb<byte>(v)
 // Machine-level pieces (isa/gfx950_ops.h): imin3 / imed3 / imax3, bl_vgpr + bl_fb (taps in vector registers, bytes converted
@@ -591,6 +603,8 @@ __global__ __launch_bounds__(256, BIN_KERNEL ? BL_WAVES_BIN : BL_WAVES) void k_b
     int* flag = band_flags ? band_flags + ((size_t)b * mb_bands_y(g.hmax) + tl.ty) * mb_bands_x(g.wmax) + cgp : nullptr;
     if (BIN_KERNEL) {
         // the speculative walk; a band that turns out not to be two-valued is flagged and left to the general kernel behind this one
+        // (k_grey has flagged the bands in which it saw such a pixel already)
+        if (*flag != 0) return;
         if (!walk(std::true_type{}) && lane == 0) *flag = 1;
     } else {
         if (flag != nullptr && *flag == 0) return;                    // the two-valued kernel has written all six planes of this band
