@@ -264,6 +264,43 @@ def test_jpeg_decode_matches_pillow(lib):
     det.close()
 
 
+def test_canny_byte_walk_emulated(lib):
+    """Round 4: Sobel + suppression of two-valued bands in bytes, restarts in 16-bit pairs -- the emulated twin of
+    tests/test_gpu_parity.py::test_canny_byte_walk_shapes_thresholds_and_restarts (small shapes, the thresholds around the multiples of
+    255 the byte walk compares in, a stray grey pixel in the middle of a band and in the apron of the next)."""
+    from oracle import cv_oracle as cvo
+    rng = np.random.default_rng(405)
+
+    def check(det, imgs, prm):
+        det.detect_batch(imgs, prm, full=False)
+        hc_lo = max(1, prm.hc_param1 // 2)
+        for i, im in enumerate(imgs):
+            np.testing.assert_array_equal(det.fetch_plane(i, "edges"), cvo.canny(im, prm.canny_lo, prm.canny_hi), err_msg="edges %s %s" % (im.shape, prm))
+            for v, name in enumerate(parity.VARIANT_PLANES):
+                want = cvo.canny(det.fetch_plane(i, name), hc_lo, prm.hc_param1)
+                got = (det.fetch_plane(i, 9 + 1 + v) == 2).astype(np.uint8) * 255
+                np.testing.assert_array_equal(got, want, err_msg="%s %s %s" % (name, im.shape, prm))
+
+    det = Detector(0, 2, 264, 70, lib=lib)
+    det.set_debug(True)
+    shapes = [(1, 1), (3, 5), (9, 4), (34, 257), (66, 13), (40, 260)]
+    imgs = []
+    for k, (h, w) in enumerate(shapes):
+        im = np.where(rng.random((h, w)) < (0.5, 0.15)[k % 2], 0, 255).astype(np.uint8)
+        if h > 20:
+            im[h // 3:h // 3 + 3, :] = 0; im[:, w // 2:w // 2 + 2] = 255
+        imgs.append(im)
+    for prm in (Params(), Params(canny_lo=254, canny_hi=255, hc_param1=510), Params(canny_lo=-5, canny_hi=0, hc_param1=1),
+                Params(canny_lo=255, canny_hi=1275, hc_param1=1021)):
+        for k in range(0, len(imgs), 2):
+            check(det, imgs[k:k + 2], prm)
+    base = imgs[3]
+    a = base.copy(); a[17, 255] = 77
+    b = base.copy(); b[32, 3] = 254
+    check(det, [a, b], Params())
+    det.close()
+
+
 def test_blur_bank_shapes_emulated(lib):
     """k_blur's border machinery (byte permutations of the lane's dword triple, reflect / replicate rows, the 7-row ring)
     and the bit-plane medians on awkward shapes -- the emulated twin of tests/test_gpu_parity.py::test_blur_bank_shapes."""

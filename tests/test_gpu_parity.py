@@ -451,6 +451,73 @@ def test_two_valued_band_speculation_restarts():
     det.close()
 
 
+def _canny_maps_match(det, imgs, params):
+    """edge image (main Canny) and the eight HoughCircles Canny maps of every image against the oracle's Canny of the same plane."""
+    det.detect_batch(imgs, params, full=False)
+    hc_lo = max(1, params.hc_param1 // 2)
+    for i, im in enumerate(imgs):
+        want = cvo.canny(im, params.canny_lo, params.canny_hi)
+        got = det.fetch_plane(i, "edges")
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, "edges of image %d %s (%s) differ at %d px, first %s" % (i, im.shape, params, len(bad), bad[0])
+        for v, name in enumerate(parity.VARIANT_PLANES):
+            plane = det.fetch_plane(i, name)
+            want = cvo.canny(plane, hc_lo, params.hc_param1)
+            got = (det.fetch_plane(i, 9 + 1 + v) == 2).astype(np.uint8) * 255
+            bad = np.argwhere(got != want)
+            assert len(bad) == 0, "HoughCircles Canny of %s, image %d %s (%s) differs at %d px, first %s" % (
+                name, i, im.shape, params, len(bad), bad[0])
+
+
+def test_canny_byte_walk_shapes_thresholds_and_restarts():
+    """Round 4: bands of pure 0 / 255 pixels take Sobel + suppression in bytes (k_sobel_nms_rows, BIN), everything else and every band
+    whose walk meets another value in 16-bit pairs -- the second walk overwrites the first.  0 / 255 images on the awkward shapes (the
+    4-pixel lane, the 256-pixel wavefront whose end lanes compute a neighbour's magnitude themselves, the 32-row band), thresholds
+    around the multiples of 255 the byte walk compares in (and below 0, and above 8 x 255 where nothing passes), fused and separate
+    main Canny, and stray grey pixels that stop a walk in its first row, in the middle, in its last rows and in the apron it shares
+    with the next band / the next wavefront."""
+    rng = np.random.default_rng(404)
+    shapes = [(1, 1), (2, 3), (3, 2), (5, 4), (4, 5), (9, 9), (31, 255), (32, 256), (33, 257), (34, 258), (35, 259), (64, 260),
+              (70, 511), (40, 513), (66, 1023), (67, 1024), (68, 1025), (100, 1030)]
+    imgs = []
+    for k, (h, w) in enumerate(shapes):
+        dens = (0.5, 0.1, 0.9)[k % 3]
+        im = np.where(rng.random((h, w)) < dens, 0, 255).astype(np.uint8)
+        if h > 20 and w > 20:                                # some structure: bars, a disc, constant regions
+            im[h // 3:h // 3 + 3, :] = 0; im[:, w // 2:w // 2 + 2] = 255
+            yy, xx = np.mgrid[0:h, 0:w]
+            im[(yy - h // 2) ** 2 + (xx - w // 3) ** 2 < (min(h, w) // 4) ** 2] = 0
+        imgs.append(im)
+    det = Detector(0, 6, 1032, 100)
+    det.set_debug(True)
+    param_sets = [Params(), Params(canny_lo=100, canny_hi=200), Params(canny_lo=-5, canny_hi=0, hc_param1=1),
+                  Params(canny_lo=254, canny_hi=255, hc_param1=510), Params(canny_lo=255, canny_hi=256, hc_param1=511),
+                  Params(canny_lo=509, canny_hi=1020, hc_param1=1021), Params(canny_lo=1275, canny_hi=2039, hc_param1=2040),
+                  Params(canny_lo=2040, canny_hi=3000, hc_param1=4100), Params(canny_lo=0, canny_hi=0, hc_param1=3)]
+    for pi, prm in enumerate(param_sets):
+        for k in range(0, len(imgs), 6):
+            if pi < 2 or k % 12 == (pi % 2) * 6:
+                _canny_maps_match(det, imgs[k:k + 6], prm)
+    # restarts: one stray pixel per image
+    h, w = 100, 600
+    base = np.where(rng.random((h, w)) < 0.4, 0, 255).astype(np.uint8)
+    base[50:60, 100:500] = 0
+    spots = [(0, 0, 128), (1, 5, 3), (2, 300, 254), (17, 255, 1), (31, 256, 77), (32, 10, 200), (33, 259, 100), (30, 511, 90),
+             (61, 252, 2), (63, 599, 129), (64, 3, 60), (65, 512, 250), (95, 257, 127), (99, 599, 5), (99, 0, 251), (66, 260, 33)]
+    for k in range(0, len(spots), 4):
+        batch = []
+        for (y, x, v) in spots[k:k + 4]:
+            im = base.copy(); im[y, x] = v
+            batch.append(im)
+        _canny_maps_match(det, batch, Params())
+        _canny_maps_match(det, batch, Params(canny_lo=100))
+    # the same through the colour front end: channels equal (-> the grey plane's walk) and one coloured pixel (-> the 3-plane mode)
+    rgb = np.repeat(base[:, :, None], 3, axis=2)
+    rgb2 = rgb.copy(); rgb2[40, 300] = (255, 0, 0)
+    _canny_maps_match(det, [rgb, rgb2], Params())
+    det.close()
+
+
 def test_plain_rounding_gaussian_taps_use_the_integer_kernels():
     """gauss_kernel_mode = 1 can give tap sums of 257, outside the float kernel's exactness condition: the
     integer kernels take over and still match the oracle."""
