@@ -580,7 +580,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         rc = run_hysteresis(ctx, 1, fx * fy * nb * NVAR);
         if (rc) return rc;
         // -- kernel group 8 of i2s_last_kernel_timing
-        I2S_LAUNCH(8, k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), dim3(EBT), ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
+                I2S_LAUNCH(8, k_edge_bins, dim3((unsigned)ebx * eby * nb * NVAR), dim3(EBT), ctx->d_desc, g, grey, map0 + (size_t)nb * g.slot,
                            ctx->d_bin_ent, ctx->d_bin_cnt, ebx, eby);
         // -- kernel group 9 of i2s_last_kernel_timing
         // the reference's radius range (1 .. 30) gets the variant whose radius loop is unrolled

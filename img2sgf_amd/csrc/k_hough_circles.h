@@ -50,59 +50,80 @@ __global__ __launch_bounds__(EBT) void k_edge_bins(const ImgDesc* __restrict__ d
                                                    const uint8_t* __restrict__ planes, const uint8_t* __restrict__ maps,
                                                    uint2* __restrict__ bin_ent, int* __restrict__ bin_cnt, int gx, int gy)
 {
-    // one block = 4 x 1 bins (128 x 32 pixels); two 16-byte map loads per thread, both in flight together (the kernel is
-    // latency-bound: load -> compact -> gather -> store).  Edge positions are first compacted into an LDS list (13-bit
-    // tile-local coordinates) so that the gradient work (8 neighbour loads, sqrt, 2 divides) is spread evenly over the
-    // block instead of serialising inside the few threads whose pixels lie on a line.
-    __shared__ unsigned short s_list[EBB_X * EBB_Y * EB * EB];
-    __shared__ int s_nl;
+    // one block = 4 x 1 bins (128 x 32 pixels); two 16-byte map loads per thread (rows ly and ly + 16), both in flight together.
+    // Round 4 (the SQ counters of round 3's kernel: 559 vector instructions per wavefront at 100 % of the SIMD cycles -- bound by its
+    // arithmetic, not by the latencies its structure suggests): the edge pixels of a thread's 32 become a 32-bit MASK in ~25
+    // instructions (bit 1 of a map byte says "== 2"; the four dwords of a load are OR-ed into the four low bits of each byte), the
+    // masks' population counts are prefix-summed over the block, and edge pixel i of the block is found by the thread that will do
+    // its gradient: a binary search over the 128 prefix sums, then the j-th set bit of that mask.  Round 3 tested every byte of
+    // every dword in every wavefront (one lane with an edge in that dword sufficed) and appended through one LDS counter.
+    static_assert(EB_NLD == 2 && EBT == 128 && EB_RPI == 16, "mask layout below: two rows of 16 pixels per thread");
+    __shared__ unsigned s_mask[EBT];
+    __shared__ unsigned short s_pre[EBT];          // inclusive prefix sums of the masks' population counts (<= 4096)
+    __shared__ int s_wtot[EBT / 64];
     __shared__ int s_n[EBB_X * EBB_Y];
-    const TileId tl = tile_of_block(gx, gy);
+    const TileId tl = tile_of_block(gx, gy);               // (a plain 3-D grid in natural order: 3.9 -> 5.4 us, profiles/r04_d_edge_bins.txt)
     const int b = tl.z / NVAR, v = tl.z % NVAR;
     const int w = desc[b].w, h = desc[b].h;
     const int x0 = tl.tx * (EBB_X * EB), y0 = tl.ty * (EBB_Y * EB);
     if (x0 >= w || y0 >= h) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t off = ((size_t)v * g.nb + b) * g.slot;
     const uint8_t* plane = v == 0 ? desc[b].grey : planes + off;      // variant 0 may be the source image itself (ImgDesc::grey)
     const int ppitch = v == 0 ? desc[b].gpitch : g.pitch;
     const uint8_t* map = maps + off;
     const size_t bin0 = (size_t)(b * NVAR + v) * g.bins + (size_t)tl.ty * EBB_Y * g.bw + (size_t)tl.tx * EBB_X;
     if (tid < EBB_X * EBB_Y) s_n[tid] = 0;
-    if (tid == 32) s_nl = 0;
-    __syncthreads();
+    // mask bit 8 q + d + 4 r  <=>  pixel 4 d + q of the thread's 16 in row ly + 16 r is an edge
+    const int ly = tid >> 3, c16 = (tid & 7) * 16;
+    const int xs = x0 + c16;
+    unsigned M = 0;
     {
-        const int ly = tid >> 3, c16 = (tid & 7) * 16;
-        const int xs = x0 + c16;
-        uint4 m16[EB_NLD];
+        uint4 m16[2];
 #pragma unroll
-        for (int r = 0; r < EB_NLD; r++) {
+        for (int r = 0; r < 2; r++) {
             const int y = y0 + ly + r * EB_RPI;
             m16[r] = make_uint4(0u, 0u, 0u, 0u);
             if (y < h && xs < w) m16[r] = *reinterpret_cast<const uint4*>(map + rowoff(y, g.pitch) + xs);
         }
 #pragma unroll
-        for (int r = 0; r < EB_NLD; r++) {
-            const unsigned mw[4] = {m16[r].x, m16[r].y, m16[r].z, m16[r].w};
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const unsigned m4 = mw[d];
-                const unsigned t = m4 ^ 0x02020202u;
-                if (((t - 0x01010101u) & ~t & 0x80808080u) == 0) continue;      // no byte == 2
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int lx = c16 + 4 * d + q;
-                    if (x0 + lx < w && ((m4 >> (8 * q)) & 0xffu) == 2u)
-                        s_list[atomicAdd(&s_nl, 1)] = (unsigned short)(lx | ((ly + r * EB_RPI) << 7));
-                }
-            }
+        for (int r = 0; r < 2; r++) {
+            const unsigned t0 = m16[r].x & 0x02020202u, t1 = m16[r].y & 0x02020202u, t2 = m16[r].z & 0x02020202u, t3 = m16[r].w & 0x02020202u;
+            const unsigned t3a = t3 + t3;
+            const unsigned u = bitop3<0xFE>(t0 >> 1, t1, t2 + t2) | (t3a + t3a);
+            M |= r ? u << 4 : u;
+        }
+        if (xs + 16 > w) {                                   // the image ends inside these 16 pixels
+            unsigned keep = 0;
+            for (int p = 0; p < 16; p++) if (xs + p < w) keep |= 0x11u << (8 * (p & 3) + (p >> 2));
+            M &= keep;
         }
     }
+    {
+        int pre = __popc(M);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, (unsigned)o); if (lane >= o) pre += t; }
+        if (lane == 63) s_wtot[wave] = pre;
+        __syncthreads();
+        if (wave == 1) pre += s_wtot[0];
+        s_pre[tid] = (unsigned short)pre;
+        s_mask[tid] = M;
+    }
     __syncthreads();
-    const int nl = s_nl;
+    const int nl = s_pre[EBT - 1];
     for (int i = tid; i < nl; i += EBT) {
-        const int le = s_list[i];
-        const int lx = le & 127, lyy = le >> 7;
+        int lo = 0;
+#pragma unroll
+        for (int s = EBT / 2; s >= 1; s >>= 1) if ((int)s_pre[lo + s - 1] <= i) lo += s;
+        int j = i - (lo ? (int)s_pre[lo - 1] : 0);
+        unsigned m = s_mask[lo];
+        int pos = 0, c;
+        c = __popc(m & 0xffffu); if (j >= c) { j -= c; m >>= 16; pos = 16; }
+        c = __popc(m & 0xffu);   if (j >= c) { j -= c; m >>= 8; pos += 8; }
+        c = __popc(m & 0xfu);    if (j >= c) { j -= c; m >>= 4; pos += 4; }
+        c = __popc(m & 0x3u);    if (j >= c) { j -= c; m >>= 2; pos += 2; }
+        if (j >= (int)(m & 1u)) pos += 1;
+        const int lx = (lo & 7) * 16 + 4 * (pos & 3) + (pos >> 3), lyy = (lo >> 3) + EB_RPI * ((pos >> 2) & 1);
         const int x = x0 + lx, y = y0 + lyy;
         int dx, dy;
         if (x >= 1 && y >= 1 && y <= h - 2 && (x <= w - 3 || (x == w - 2 && y <= h - 3))) {
