@@ -102,6 +102,9 @@ struct i2s_ctx {
     i2s_result* d_res = nullptr;
     i2s_board* d_boards = nullptr;
     i2s_board* h_boards = nullptr;
+    // full records: what is in use of each is packed on the device (k_pack_results) and crosses the bus in ONE copy into pinned memory
+    uint8_t* d_pack = nullptr; uint8_t* h_pack = nullptr; size_t pack_cap = 0;
+    unsigned long long* d_pack_off = nullptr; unsigned long long* h_pack_off = nullptr;     // [nb] byte offset of image i's packed record
     i2s_board* d_sink = nullptr;    // i2s_set_board_sink: device array that also receives image i's record at [i]
     int* d_dbg_acc = nullptr;
     int debug = 0;
@@ -194,9 +197,9 @@ extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;
     void* dev[] = {ctx->d_planes, ctx->d_src, ctx->d_desc, ctx->d_flags, ctx->d_cent_list, ctx->d_counts, ctx->d_est_keys,
-                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_hmark, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_colour, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus};
+                   ctx->d_vcirc, ctx->d_lacc, ctx->d_res, ctx->d_boards, ctx->d_dbg_acc, ctx->d_bin_ent, ctx->d_bin_cnt, ctx->d_weak, ctx->d_chg, ctx->d_hmark, ctx->d_tl_cnt, ctx->d_tl_idx, ctx->d_mflags, ctx->d_colour, ctx->d_lsum, ctx->d_xf, ctx->d_raw, ctx->d_jpg, ctx->d_jd, ctx->d_jh, ctx->d_je, ctx->d_jstatus, ctx->d_pack, ctx->d_pack_off};
     for (void* q : dev) if (q) (void)hipFree(q);
-    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob, ctx->h_coef.p};
+    void* host[] = {ctx->h_desc, ctx->h_flags, ctx->h_boards, ctx->h_xf, ctx->h_jd, ctx->h_jstatus, ctx->h_jflag, ctx->h_jblob, ctx->h_coef.p, ctx->h_pack, ctx->h_pack_off};
     for (void* q : host) if (q) (void)hipHostFree(q);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (ProfPair& pp : ctx->prof_pairs) { (void)hipEventDestroy(pp.start); (void)hipEventDestroy(pp.stop); }
@@ -349,6 +352,22 @@ static int hough_trig(const i2s_params* p, HoughTrig* t)
         }
     }
     return I2S_OK;
+}
+
+// The used parts of the full records of a pass, packed: per image [the record up to `circles` + n_circles circles][n_circles kept flags,
+// padded to 4][detected + board], at byte offset off[i] of `out` (run_pass computes the offsets from the board records it already has).
+__global__ __launch_bounds__(256) void k_pack_results(const i2s_result* __restrict__ res, const unsigned long long* __restrict__ off,
+                                                      uint8_t* __restrict__ out)
+{
+    const i2s_result* r = res + blockIdx.x;
+    const unsigned n = (unsigned)r->n_circles;
+    const unsigned* s32 = reinterpret_cast<const unsigned*>(r);
+    unsigned* d32 = reinterpret_cast<unsigned*>(out + off[blockIdx.x]);
+    const unsigned head = (unsigned)(offsetof(i2s_result, circles) / 4) + n * 3, kept = (n + 3) / 4;
+    const unsigned tail = (unsigned)((sizeof(i2s_result) - offsetof(i2s_result, detected)) / 4);
+    for (unsigned i = threadIdx.x; i < head; i += 256) d32[i] = s32[i];
+    for (unsigned i = threadIdx.x; i < kept; i += 256) d32[head + i] = s32[offsetof(i2s_result, circle_kept) / 4 + i];
+    for (unsigned i = threadIdx.x; i < tail; i += 256) d32[head + kept + i] = s32[offsetof(i2s_result, detected) / 4 + i];
 }
 
 static int check_params(const i2s_params* p)
@@ -652,16 +671,42 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         // The full record is 233 KB, nearly all of it the circle arrays' capacity: only what is in use crosses the bus -- the part
         // in front of the circles, n_circles circles, n_circles kept flags, the two boards behind them (the board record, already
         // on the host, says how many circles there are).  Array entries beyond the counts are left as the caller had them.
-        for (int i = 0; i < nb; i++) {
-            const size_t n = ctx->h_boards[i].n_circles;
-            const uint8_t* src = reinterpret_cast<const uint8_t*>(ctx->d_res + i);
-            uint8_t* out = reinterpret_cast<uint8_t*>(full + dst[i]);
-            I2S_HIP(hipMemcpyAsync(out, src, offsetof(i2s_result, circles) + n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
-            if (n) I2S_HIP(hipMemcpyAsync(out + offsetof(i2s_result, circle_kept), src + offsetof(i2s_result, circle_kept), n, hipMemcpyDeviceToHost, st));
-            I2S_HIP(hipMemcpyAsync(out + offsetof(i2s_result, detected), src + offsetof(i2s_result, detected),
-                                   sizeof(i2s_result) - offsetof(i2s_result, detected), hipMemcpyDeviceToHost, st));
+        // The used parts are packed on the device and come over in one copy into pinned memory (three copies per image
+        // into the caller's pageable records serialised, 3 x nb calls per pass).
+        constexpr size_t HEAD = offsetof(i2s_result, circles), TAIL = sizeof(i2s_result) - offsetof(i2s_result, detected);
+        static_assert(HEAD % 4 == 0 && offsetof(i2s_result, circle_kept) % 4 == 0 && offsetof(i2s_result, detected) % 4 == 0 && TAIL % 4 == 0, "dword copies");
+        if (!ctx->h_pack_off) {
+            I2S_HIP(hipHostMalloc(&ctx->h_pack_off, (size_t)ctx->geo.nb * sizeof(unsigned long long)));
+            I2S_HIP(hipMalloc(&ctx->d_pack_off, (size_t)ctx->geo.nb * sizeof(unsigned long long)));
         }
+        size_t total = 0;
+        for (int i = 0; i < nb; i++) {
+            const size_t n = (size_t)ctx->h_boards[i].n_circles;
+            ctx->h_pack_off[i] = total;
+            total += HEAD + n * 12 + ((n + 3) & ~(size_t)3) + TAIL;
+        }
+        if (total > ctx->pack_cap) {
+            if (ctx->d_pack) { (void)hipFree(ctx->d_pack); ctx->d_pack = nullptr; }
+            if (ctx->h_pack) { (void)hipHostFree(ctx->h_pack); ctx->h_pack = nullptr; }
+            ctx->pack_cap = 0;
+            const size_t want = total + total / 4;
+            I2S_HIP(hipMalloc(&ctx->d_pack, want));
+            I2S_HIP(hipHostMalloc(&ctx->h_pack, want));
+            ctx->pack_cap = want;
+        }
+        I2S_HIP(hipMemcpyAsync(ctx->d_pack_off, ctx->h_pack_off, nb * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_pack_results, dim3(nb), dim3(256), 0, st, ctx->d_res, ctx->d_pack_off, ctx->d_pack);
+        I2S_HIP(hipGetLastError());
+        I2S_HIP(hipMemcpyAsync(ctx->h_pack, ctx->d_pack, total, hipMemcpyDeviceToHost, st));
         I2S_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < nb; i++) {
+            const size_t n = (size_t)ctx->h_boards[i].n_circles;
+            const uint8_t* src = ctx->h_pack + ctx->h_pack_off[i];
+            uint8_t* out = reinterpret_cast<uint8_t*>(full + dst[i]);
+            memcpy(out, src, HEAD + n * 12);
+            memcpy(out + offsetof(i2s_result, circle_kept), src + HEAD + n * 12, n);
+            memcpy(out + offsetof(i2s_result, detected), src + HEAD + n * 12 + ((n + 3) & ~(size_t)3), TAIL);
+        }
     }
     float ms;
     for (int i = 0; i < 4; i++) {
