@@ -158,16 +158,12 @@ __global__ __launch_bounds__(256) void k_sobel_nms_rows(const ImgDesc* __restric
     static_assert((CR_R + 4) % 6 == 0, "the row loop is unrolled by the ring depths (3 and 2)");
     const int t_end = imin(CR_R + 4, h + 2 - (y0 - 2));               // input rows beyond h + 1 feed no output of this band
     if constexpr (BIN && NC == 1) {
-        #ifdef I2S_EXP_NOBIN
-        bool try_bytes = false;                                        // experiment builds only (-DI2S_EXP_NOBIN)
-#else
         // not tried: Gaussian planes (never two-valued, short of a constant image); the grey plane and the medians of a flagged band
         // (band_flags: the HoughCircles dispatch runs behind k_blur and sees its verdicts, the main Canny runs before it and sees what
         // k_grey flagged -- nothing for sources that are their own grey plane); bands whose first row already fails
         bool try_bytes = !(main_mode == 0 && v >= 3 && (v & 1));
         if (try_bytes && !(main_mode == 0 && v == 1) && band_flags != nullptr)
             try_bytes = band_flags[((size_t)b * mb_bands_y(g.hmax) + (y0 / MB_R)) * mb_bands_x(g.wmax) + cgp] == 0;
-#endif
         unsigned ve = 0;                                                // pixels of the end-lane dword that exist (the two-valued test looks at them too)
         if (has_e) {
 #pragma unroll
