@@ -85,7 +85,7 @@ assert C.sizeof(I2sBoard) == 384
 assert C.sizeof(I2sResult) == 73384 + (16384 - 4096) * 13
 
 EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
-           "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_jpeg_info", "i2s_detect_jpeg_batch", "i2s_jpeg_last_rounds", "i2s_jpeg_set_max_rounds", "i2s_jpeg_last_timing",
+           "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_jpeg_info", "i2s_detect_jpeg_batch", "i2s_jpeg_last_rounds", "i2s_jpeg_last_handed_back", "i2s_jpeg_set_max_rounds", "i2s_jpeg_last_timing",
            "i2s_classify_batch", "i2s_grid_from_lines", "i2s_validate_grid", "i2s_find_lines",
            "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc",
            "i2s_comm_unique_id", "i2s_comm_create", "i2s_comm_destroy", "i2s_comm_last_error", "i2s_comm_shard", "i2s_comm_all",
@@ -131,6 +131,7 @@ class I2sLibrary:
                                           C.POINTER(I2sParams), C.POINTER(I2sBoard), C.POINTER(I2sResult)]
         L.i2s_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, ip, ip, ip]
         L.i2s_jpeg_last_rounds.argtypes = [vp]
+        L.i2s_jpeg_last_handed_back.argtypes = [vp]
         L.i2s_jpeg_set_max_rounds.argtypes = [vp, C.c_int]
         L.i2s_jpeg_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
         L.i2s_detect_jpeg_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(I2sXform),

@@ -184,18 +184,18 @@ static int jpeg_lanes(i2s_ctx* ctx, const std::vector<int>& list, const std::vec
     return I2S_OK;
 }
 
-constexpr int JE_MAX_ROUNDS = 1 << 16;     // room in the flag array; the context's je_max_rounds (2048) is the working limit
+constexpr int JE_MAX_ROUNDS = 1 << 16;     // room in the flag array; the context's je_max_rounds (48) is the working limit
 constexpr int JE_MAX_SEGS = 1 << 16;       // restart intervals per scan handled on the device
 
 // Sequential files of `list`, parallel inside each scan.  Files whose entropy-coded data hold more than stuffed bytes and RSTn
-// markers are moved to `others`.  On return the kernels have run (ctx->d_jstatus holds the verdicts; `converged` is false if
-// the iteration hit its cap: the caller decodes the list elsewhere).
+// markers are moved to `others`, and so are -- round 4, per FILE instead of per pass -- the files whose iteration has not reached its
+// fixed point at the limit (a blank page: one subsequence per round): the others are done.  On return the kernels have run
+// (ctx->d_jstatus holds the verdicts of the files still in `list`).
 // dev_scans[i] (out): how many scans of file i the device decodes -- all of a sequential file, the scans in front of the first
 // refinement pass of a progressive one (the host threads take over from there, jpeg_host_finish).
 static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>& others, const std::vector<JpegFile>& files, const int* order,
-                         bool* converged, std::vector<int>& dev_scans)
+                         std::vector<int>& dev_scans)
 {
-    *converged = true;
     std::vector<JpegHuff> tabs;
     std::vector<JeScan> scans;
     std::vector<JeSeg> segs;
@@ -248,6 +248,15 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
             ok = sc.clean && need <= JE_MAX_SEGS;
             if (ok && (long long)sc.rst.size() + 1 < need) return jpeg_bad(ctx, order[i]);        // a restart marker is missing
             bytes += sc.len + 4 * (size_t)need;
+            // A sequential scan of next to nothing but empty blocks (a blank page: 5.6 bits per block, DC code + EOB; anything drawn
+            // costs tens) never resynchronises a guessed parse -- the iteration would advance one subsequence per round up to its
+            // limit and hand the file back then (0.7 ms per round: one lane decodes 170 blocks).  Such a file is a few thousand code
+            // words for the serial decoder: it goes there at once.  (Progressive files: their DC passes are legitimately this short.)
+            if (ok && !f.progressive && !sc.dri) {
+                long long bpm = 1;
+                if (!single) { bpm = 0; for (int k = 0; k < sc.ns; k++) bpm += (long long)f.c[sc.ci[k]].h * f.c[sc.ci[k]].v; }
+                if ((long long)sc.len * 8 < 8 * mcus * bpm && sc.len > (size_t)ctx->je_max_rounds * JE_SUB_BYTES) ok = false;
+            }
         }
         if (!ok || bo + bytes >= (1ull << 31)) { others.push_back(i); continue; }
         kept.push_back(i);
@@ -348,9 +357,26 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     // the flag of the last one is read back
     uint32_t round = 0;
     int burst = 3;
+    std::vector<int> handed;                    // files handed back at the limit
     for (;;) {
         const int left = ctx->je_max_rounds - (int)round;
-        if (left <= 0) { *converged = false; return I2S_OK; }
+        if (left <= 0) {
+            // the limit: which files still have work scheduled?  They go to the serial decoder (whatever k_je_write leaves of them
+            // below is replaced by its upload, their verdicts are reset); every other file's states are final
+            int* d_pend = ctx->d_jstatus;                       // (zeroed by the caller; k_je_scan / k_je_write have not run yet)
+            hipLaunchKernelGGL(k_je_pending, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_stamp, round, d_pend);
+            I2S_HIP(hipGetLastError());
+            I2S_HIP(hipMemcpyAsync(ctx->h_jstatus, d_pend, (size_t)ctx->max_batch * sizeof(int), hipMemcpyDeviceToHost, st));
+            I2S_HIP(hipMemsetAsync(d_pend, 0, (size_t)ctx->max_batch * sizeof(int), st));
+            const double t1 = now_ms();
+            I2S_HIP(hipStreamSynchronize(st));
+            ctx->jpeg_ms[2] += (float)(now_ms() - t1);
+            for (size_t k = 0; k < list.size();) {
+                if (ctx->h_jstatus[list[k]]) { handed.push_back(list[k]); others.push_back(list[k]); list.erase(list.begin() + (long)k); }
+                else k++;
+            }
+            break;
+        }
         for (int n = 0; n < std::min(burst, left); n++, round++)
             hipLaunchKernelGGL(k_je_sync, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_tabs, d_blob, d_E, d_stamp, d_acc, d_flag, round);
         I2S_HIP(hipMemcpyAsync(ctx->h_jflag, d_flag + (round - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -361,9 +387,16 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
         burst = round < 16 ? 2 : 8;
     }
     ctx->je_rounds = (int)round;
+    ctx->je_handed_back = (int)handed.size();
     hipLaunchKernelGGL(k_je_scan, dim3(cdiv((int)segs.size(), 4)), dim3(256), 0, st, d_segs, (int)segs.size(), d_acc, d_base, ctx->d_jstatus);
     hipLaunchKernelGGL(k_je_write, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_tabs, d_blob, d_E, d_base, ctx->d_jstatus);
     I2S_HIP(hipGetLastError());
+    for (int i : handed) {
+        // an unfinished parse has no verdict, and what it wrote is wiped: the serial decoders start from zeroed coefficients
+        I2S_HIP(hipMemsetAsync(ctx->d_jstatus + i, 0, sizeof(int), st));
+        for (int c = 0; c < files[i].ncomp; c++)
+            I2S_HIP(hipMemsetAsync(const_cast<int16_t*>(ctx->h_jd[i].coef[c]), 0, (size_t)files[i].c[c].bw * files[i].c[c].bh * 64 * sizeof(int16_t), st));
+    }
     return I2S_OK;
 }
 
@@ -372,6 +405,7 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
 {
     std::vector<int> par, host, lanes, late;
     ctx->je_rounds = 0;
+    ctx->je_handed_back = 0;
     const double t_in = now_ms();
     const float w_in = ctx->jpeg_ms[2];
     struct Span { i2s_ctx* c; double t; float w; ~Span() { c->jpeg_ms[1] += (float)(now_ms() - t) - (c->jpeg_ms[2] - w); } } span{ctx, t_in, w_in};
@@ -390,17 +424,10 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     if (!host.empty()) need_coef();
     if (coef_rc) return coef_rc;
     if (!host.empty()) host_job = std::thread([&]() { host_bad = jpeg_host_decode(ctx, host, files, order, coef); });
-    bool converged = true;
     std::vector<int>& rest = mode == 2 ? lanes : late;          // files the parallel decoder hands back
     std::vector<int> dev_scans((size_t)nb, 0);
-    int rc = jpeg_parallel(ctx, par, rest, files, order, &converged, dev_scans);
+    int rc = jpeg_parallel(ctx, par, rest, files, order, dev_scans);
     if (rc) return rc;
-    if (!converged) {
-        rest.insert(rest.end(), par.begin(), par.end());
-        par.clear();
-        // what the unfinished iteration may have left of them is wiped: the serial decoders start from zeroed coefficients
-        I2S_HIP(hipMemsetAsync(ctx->d_jpg, 0, ncoef, ctx->stream));
-    }
     // progressive files the device has started: their coefficient arrays come to the host, which runs the remaining passes
     // (every progressive file's verdict is looked at here: JPG_REDO sends the file to the serial decoder)
     std::vector<int> prog, prog_all;
@@ -463,6 +490,7 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
 }
 
 extern "C" int i2s_jpeg_last_rounds(const i2s_ctx* ctx) { return ctx ? ctx->je_rounds : 0; }
+extern "C" int i2s_jpeg_last_handed_back(const i2s_ctx* ctx) { return ctx ? ctx->je_handed_back : 0; }
 
 extern "C" int i2s_jpeg_set_max_rounds(i2s_ctx* ctx, int rounds)
 {

@@ -85,7 +85,8 @@ struct i2s_ctx {
     size_t jblob_bytes = 0;
     JpegCoefHost h_coef;         // pinned: coefficient arrays of progressive files on their way to / from the host decoder
     int je_rounds = 0;           // rounds k_je_sync took in the last pass
-    int je_max_rounds = 2048;    // beyond this a pass is handed to the serial decoder (i2s_jpeg_set_max_rounds)
+    int je_max_rounds = 48;      // the files still iterating then are handed to the serial decoder (i2s_jpeg_set_max_rounds)
+    int je_handed_back = 0;      // how many that were in the last pass
     float jpeg_ms[4] = {0, 0, 0, 0};     // last i2s_detect_jpeg_batch: parsing | entropy stage, host work | entropy stage, waiting for the device | whole call
     int* d_tl_cnt = nullptr;     // [nb][tiles] circles whose erase box touches the tile
     TlBox* d_tl_idx = nullptr;   // [nb][tiles][TL_CAP] box, plus centre and index of the circles that touch the tile
@@ -676,8 +677,8 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         constexpr size_t HEAD = offsetof(i2s_result, circles), TAIL = sizeof(i2s_result) - offsetof(i2s_result, detected);
         static_assert(HEAD % 4 == 0 && offsetof(i2s_result, circle_kept) % 4 == 0 && offsetof(i2s_result, detected) % 4 == 0 && TAIL % 4 == 0, "dword copies");
         if (!ctx->h_pack_off) {
-            I2S_HIP(hipHostMalloc(&ctx->h_pack_off, (size_t)ctx->geo.nb * sizeof(unsigned long long)));
-            I2S_HIP(hipMalloc(&ctx->d_pack_off, (size_t)ctx->geo.nb * sizeof(unsigned long long)));
+            I2S_HIP(hipHostMalloc(&ctx->h_pack_off, (size_t)ctx->max_batch * sizeof(unsigned long long)));
+            I2S_HIP(hipMalloc(&ctx->d_pack_off, (size_t)ctx->max_batch * sizeof(unsigned long long)));
         }
         size_t total = 0;
         for (int i = 0; i < nb; i++) {

@@ -266,6 +266,17 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_sync(const JeScan* __restrict__
     }
 }
 
+// grid (blocks of the pass), block JE_BLOCK: pend[file] = 1 for the files that still have a subsequence scheduled for round `round`
+// (run when the iteration stops at its limit: only those files go to the serial decoder, the others have reached their fixed point)
+__global__ __launch_bounds__(JE_BLOCK) void k_je_pending(const JeScan* __restrict__ scans, const JeSeg* __restrict__ segs, const int* __restrict__ blk_scan,
+                                                          const uint32_t* __restrict__ stamp, uint32_t round, int* __restrict__ pend)
+{
+    const JeScan& sc = scans[blk_scan[blockIdx.x]];
+    const uint32_t g = blockIdx.x * JE_BLOCK + threadIdx.x;
+    if (g - sc.sub0 >= sc.nsub || stamp[g] != round) return;
+    pend[segs[je_find_seg(segs, sc, g)].file] = 1;
+}
+
 // grid (segments of the pass / 4), block 256: one wave per segment.  base[g] = blocks completed and DC sums before subsequence
 // g (running sums of accs over the segment); a segment whose parse holds fewer blocks than its interval marks the file bad.
 __global__ __launch_bounds__(256) void k_je_scan(const JeSeg* __restrict__ segs, int nseg, const JeAcc* __restrict__ accs, JeAcc* __restrict__ base,

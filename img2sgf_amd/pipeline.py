@@ -258,6 +258,10 @@ class Detector:
         """Rounds the parallel entropy decoder's iteration took in the last pass (0 = it did not run)."""
         return int(self.lib.dll.i2s_jpeg_last_rounds(self._ctx))
 
+    def jpeg_last_handed_back(self) -> int:
+        """Files of the last JPEG pass the parallel entropy decoder handed to the serial one at its round limit."""
+        return int(self.lib.dll.i2s_jpeg_last_handed_back(self._ctx))
+
     def jpeg_set_max_rounds(self, rounds: int):
         """Limit of the parallel entropy decoder's iteration; a pass that needs more goes to the serial decoder."""
         self._check(self.lib.dll.i2s_jpeg_set_max_rounds(self._ctx, int(rounds)))

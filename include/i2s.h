@@ -233,8 +233,11 @@ int  i2s_detect_jpeg_batch(i2s_ctx* ctx, int B, const uint8_t* const* jpeg, cons
 /* Rounds the parallel entropy decoder's iteration took in the last pass of the last i2s_detect_jpeg_batch call (0: it did not
  * run -- mode 0, or no sequential file in the pass).  Diagnostic. */
 int  i2s_jpeg_last_rounds(const i2s_ctx* ctx);
-/* The iteration's limit (default 2048 rounds; a pass that needs more -- a stream of identical blocks tens of thousands of
- * blocks long, or a crafted one -- is decoded by the serial decoder instead: host threads in mode 1, lanes in mode 2). */
+/* The iteration's limit (default 48 rounds: the reference's scans need 15-17, 1024x1024 diagrams 7-9).  The FILES that still have
+ * work scheduled then -- streams of identical blocks, e.g. a blank page (one 1024-bit subsequence per round: 129 rounds for
+ * 1024 x 1024), or crafted ones -- are decoded by the serial decoder instead (host threads in mode 1, lanes in mode 2); the other
+ * files of the pass are finished and stay on the device.  i2s_jpeg_last_handed_back: how many files of the last pass that was. */
+int  i2s_jpeg_last_handed_back(const i2s_ctx* ctx);
 int  i2s_jpeg_set_max_rounds(i2s_ctx* ctx, int rounds);
 /* Host-side wall times of the last i2s_detect_jpeg_batch call, ms: [0] marker parsing, [1] the entropy stage's host work
  * (removing the byte stuffing and building the records, or the Huffman decoding itself on host threads), [2] waiting for the

@@ -29,6 +29,16 @@ def test_small_synthetic_with_internals(lib):
     det.close()
 
 
+def test_small_pass_then_full_pass_on_one_context(lib):
+    """Round 4: per-context buffers sized on first use (the packed full records' offsets) must be sized for the CONTEXT's batch, not
+    for the pass that happens to come first: one image, then three, full records both times."""
+    det = Detector(0, 3, 320, 300, lib=lib)
+    imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in (5, 6, 7)]
+    parity.run_and_compare(det, imgs[:1])
+    parity.run_and_compare(det, imgs)
+    det.close()
+
+
 def test_multi_pass_ragged_batch(lib):
     """3 images of different sizes through a context holding 2 per device pass."""
     det = Detector(0, 2, 320, 300, lib=lib)
@@ -248,10 +258,10 @@ def test_jpeg_decode_matches_pillow(lib):
         det.detect_jpeg(odd, Params(jpeg_entropy_device=mode), full=False)
         for k, r in enumerate(odd_refs):
             np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="non-conforming progressive file %d, entropy mode %d" % (k, mode))
-    # a pass beyond the iteration's limit is handed to the serial decoder
+    # files still iterating at the limit are handed to the serial decoder
     det.jpeg_set_max_rounds(1)
     det.detect_jpeg(blobs, Params(), full=False)
-    assert det.jpeg_last_rounds() == 0
+    assert det.jpeg_last_rounds() == 1 and det.jpeg_last_handed_back() > 0
     for k, r in enumerate(refs):
         np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="jpeg %d, one round allowed" % k)
     det.jpeg_set_max_rounds(2048)

@@ -267,7 +267,51 @@ def test_fill_bytes_and_iteration_limit(on_device):
     det.detect_jpeg(files, Params(jpeg_entropy_device=on_device), full=False)
     for k, r in enumerate(refs):
         np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d, one round allowed" % k)
-    assert det.jpeg_last_rounds() == 0
+    if on_device:
+        # two files had fill bytes (never on the parallel path); the other two were still iterating after the one round
+        assert det.jpeg_last_rounds() == 1 and det.jpeg_last_handed_back() == 2
+    det.close()
+
+
+def test_degenerate_streams_go_to_the_serial_decoder_alone(on_device):
+    """Round 4: the iteration's limit works per FILE.  A stretch of empty blocks advances one 1024-bit subsequence
+    per round (identical blocks never resynchronise a wrong guess).  (a) A page that is blank for its first 800 rows and noise below:
+    at the default limit of 48 rounds it alone goes to the serial decoder, the diagrams of the same pass -- done after a handful of
+    rounds -- stay on the device; with a limit above its round count nothing is handed back.  (b) A page that is blank altogether
+    (under 8 bits per block) never enters the iteration.  Pixels equal Pillow's every time, in every entropy mode."""
+    from img2sgf_amd import synth
+    rng = np.random.default_rng(808)
+    half = np.full((1024, 1024), 255, np.uint8)
+    half[800:] = rng.integers(0, 256, (224, 1024), dtype=np.uint8)
+    blank = np.full((1024, 1024), 255, np.uint8)
+
+    def encode(imgs):
+        out = []
+        for im in imgs:
+            buf = io.BytesIO()
+            Image.fromarray(im).save(buf, "JPEG", quality=85)
+            out.append(buf.getvalue())
+        return out
+
+    diagrams = [synth.synth_diagram(3, geom=synth.GEOM_SMALL)[0], synth.synth_diagram(4, geom=synth.GEOM_SMALL)[0]]
+    det = Detector(0, 3, 1024, 1024)
+    for page, handed in ((half, 1), (blank, 0)):
+        files = encode([diagrams[0], page, diagrams[1]])
+        refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in files]
+        det.jpeg_set_max_rounds(48)
+        det.detect_jpeg(files, Params(jpeg_entropy_device=on_device), full=False)
+        for k, r in enumerate(refs):
+            np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d" % k)
+        if on_device:
+            assert det.jpeg_last_handed_back() == handed
+            assert det.jpeg_last_rounds() == 48 if handed else 0 < det.jpeg_last_rounds() < 20
+        det.jpeg_set_max_rounds(2048)
+        det.detect_jpeg(files, Params(jpeg_entropy_device=on_device), full=False)
+        for k, r in enumerate(refs):
+            np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d, 2048 rounds allowed" % k)
+        if on_device:
+            assert det.jpeg_last_handed_back() == 0
+            assert 48 < det.jpeg_last_rounds() < 400          # (the blank page too: below the limit a short stream is worth trying)
     det.close()
 
 

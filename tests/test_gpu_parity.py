@@ -451,6 +451,17 @@ def test_two_valued_band_speculation_restarts():
     det.close()
 
 
+def test_small_pass_then_full_pass_on_one_context():
+    """Per-context buffers sized on first use (the packed full records' offsets, round 4) are sized for the context's batch, not for
+    the pass that comes first: 1 image, then 6, then 2, full records every time, on one context."""
+    det = Detector(0, 6, 320, 300)
+    imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(20, 26)]
+    parity.run_and_compare(det, imgs[:1])
+    parity.run_and_compare(det, imgs)
+    parity.run_and_compare(det, imgs[2:4])
+    det.close()
+
+
 def _canny_maps_match(det, imgs, params):
     """edge image (main Canny) and the eight HoughCircles Canny maps of every image against the oracle's Canny of the same plane."""
     det.detect_batch(imgs, params, full=False)
