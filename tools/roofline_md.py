@@ -107,10 +107,10 @@ def main():
                              ("roofline_canny7.frac", b["roofline_canny7"]["frac"], N14 / c7 / 1e6 / 8.0),
                              ("k_vote_centres us per diagram", b["roofline_k5"]["us_per_image"], ac["k_vote_centres"] / images)):
             md.append("| %s | %.4f | %.4f | %.3f |" % (name, bv, tv, tv / bv))
-        md += ["", "The bench line takes its roofline passes at the END of `bench.py`, after ~12 s of sustained load on all three streams; the traces are",
-               "three-pass runs on an otherwise idle (cooler, higher-clocked) GPU, usually on another box of the pool.  The store-bound `k_blur` is the",
-               "kernel that shows it (1.60 - 1.77 us per diagram over the runs of this round, same build): the clean stage of the bench line reads up to",
-               "7 % below the traces, the compute-bound figures (Canny x 7, vote kernel) agree within 1 - 3 %.", ""]
+        md += ["", "The bench line and the traces come from different processes, usually on different boxes of the pool.  The store-bound `k_blur` is the kernel",
+               "that differs between them (1.60 - 1.77 us per diagram over the runs of this round, same build; a 400-pass run reads the same as a 3-pass",
+               "one, so it is not clocks under sustained load -- the box, and where the context's planes happen to lie): the clean stage of the two can be",
+               "up to 7 % apart, the compute-bound figures (Canny x 7, vote kernel) agree within 1 - 3 %.", ""]
     out = os.path.join(prof, tag + "_roofline.md")
     open(out, "w").write("\n".join(md))
     print("\n".join(md))
