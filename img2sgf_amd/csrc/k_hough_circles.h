@@ -233,7 +233,7 @@ __global__ __launch_bounds__(VPT) void k_vote_centres(const ImgDesc* __restrict_
                                                       unsigned* __restrict__ cent_list, int* __restrict__ cent_count,
                                                       int* __restrict__ dbg_acc, int gx, int gy)
 {
-    __shared__ unsigned s_acc[VL * VASTR];         // cell (cx, cy): dword cy * VASTR + cx; low half variant 2p, high half variant 2p + 1
+    __shared__ __attribute__((aligned(16))) unsigned s_acc[VL * VASTR];         // cell (cx, cy): dword cy * VASTR + cx; low half variant 2p, high half variant 2p + 1
     __shared__ int s_ticket;
     __shared__ unsigned s_ring[VPW][VRING];
     __shared__ int s_fill[VPW];
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(VPT) void k_vote_centres(const ImgDesc* __restrict_
     if (cx0 >= w || cy0 >= h) return;
     const int tid = threadIdx.x;
     const int bv = b * NVAR + v0;
-    for (int i = tid; i < VL * VASTR; i += VPT) s_acc[i] = 0;
+    static_assert((VL * VASTR) % 4 == 0, "the tile is zeroed in 16-byte stores");
+    for (int i = tid; i < VL * VASTR / 4; i += VPT) reinterpret_cast<uint4*>(s_acc)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) s_ticket = VPW;                  // bins 0 .. 15 are taken by the waves' first round
     __syncthreads();
     // LDS tile covers cells [lx0, lx0 + VL) x [ly0, ly0 + VL); edge pixels within max_r of it can vote into it
@@ -374,20 +375,35 @@ __global__ __launch_bounds__(VPT) void k_vote_centres(const ImgDesc* __restrict_
             }
         }
     }
-    // almost all cells hold fewer votes than the threshold in both halves and are rejected in pairs
-    for (int i = tid; i < VT * VT; i += VPT) {
-        const int ty = i / VT + 1, tx = i - (ty - 1) * VT + 1;
-        const unsigned v2 = s_acc[ty * VASTR + tx];
-        if ((int)(v2 & 0xffffu) <= acc_thr && (int)(v2 >> 16) <= acc_thr) continue;
-        const int x = lx0 + tx, y = ly0 + ty;
-        if (x >= w || x < 1 || y >= h || y < 1) continue;
+    // almost all cells hold fewer votes than the threshold in BOTH halves: four cells of a row are rejected together -- per dword
+    // (v + K) & 0x80008000 with K = 0x7fff - threshold in both halves is non-zero iff a half exceeds the threshold (a half is at
+    // most 3 x 3100 votes: no carry between the halves) -- in 4 trips of the workgroup instead of 16 with a division by VT each
+    {
+        static_assert(VT == 126 && VL == 128, "32 groups of four cells per interior row; the last group holds two cells, the apron and nothing");
+        const unsigned K = (unsigned)(0x7fff - iclamp(acc_thr, 0, 0x7fff)) * 0x00010001u;
+        for (int i = tid; i < VT * 32; i += VPT) {
+            const int ty = (i >> 5) + 1, tx0 = 1 + 4 * (i & 31);
+            const unsigned* row = s_acc + ty * VASTR + tx0;
+            const unsigned c0 = row[0], c1 = row[1], c2 = tx0 + 2 <= VT ? row[2] : 0u, c3 = tx0 + 3 <= VT ? row[3] : 0u;
+            if ((bitop3<0xFE>(c0 + K, c1 + K, c2 + K) | (c3 + K)) & 0x80008000u) {
+                const unsigned cv[4] = {c0, c1, c2, c3};
 #pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
-            const int a = hh ? (int)(v2 >> 16) : (int)(v2 & 0xffffu);
-            if (a <= acc_thr) continue;
-            if (a > I2S_CELL(tx - 1, ty, hh) && a >= I2S_CELL(tx + 1, ty, hh) && a > I2S_CELL(tx, ty - 1, hh) && a >= I2S_CELL(tx, ty + 1, hh)) {
-                const int k = atomicAdd(&cent_count[bv + hh], 1);
-                if (k < g.cent_cap) cent_list[(size_t)(bv + hh) * g.cent_cap + k] = (unsigned)x | ((unsigned)y << 16);
+                for (int q = 0; q < 4; q++) {
+                    const unsigned v2 = cv[q];
+                    if (!((v2 + K) & 0x80008000u)) continue;
+                    const int tx = tx0 + q;
+                    const int x = lx0 + tx, y = ly0 + ty;
+                    if (x >= w || x < 1 || y >= h || y < 1) continue;
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const int a = hh ? (int)(v2 >> 16) : (int)(v2 & 0xffffu);
+                        if (a <= acc_thr) continue;
+                        if (a > I2S_CELL(tx - 1, ty, hh) && a >= I2S_CELL(tx + 1, ty, hh) && a > I2S_CELL(tx, ty - 1, hh) && a >= I2S_CELL(tx, ty + 1, hh)) {
+                            const int k = atomicAdd(&cent_count[bv + hh], 1);
+                            if (k < g.cent_cap) cent_list[(size_t)(bv + hh) * g.cent_cap + k] = (unsigned)x | ((unsigned)y << 16);
+                        }
+                    }
+                }
             }
         }
     }
