@@ -65,6 +65,7 @@ def fixtures_roofline(device, copies=16):
     det.detect_batch(imgs, Params(), full=False)
     seg = det.last_kernel_timing()
     flagged, total = det.blur_band_stats()
+    hy = det.hysteresis_stats()
     det.close()
     pixels = sum(i.shape[0] * i.shape[1] for i in imgs)
     stage_s = sum(seg.get(k, 0.0) for k in BLUR_CANNY_SEGS) * 1e-3
@@ -74,6 +75,8 @@ def fixtures_roofline(device, copies=16):
             "algorithmic_bytes": 14 * pixels, "pixels": pixels, "stage_us": stage_s * 1e6,
             "bands_not_two_valued": flagged, "bands": total, "bands_not_two_valued_frac": flagged / max(total, 1),
             "kernel_us": {k: seg[k] * 1e3 for k in BLUR_CANNY_SEGS if k in seg},
+            # how often a real scan's hysteresis makes the host run a device pass again (i2s_hysteresis_stats)
+            "device_passes": hy["passes"], "device_passes_redone": hy["redone"], "hysteresis_passes_max": hy["used_max"],
             "whole_path_images_per_s_single_stream": len(imgs) / (sum(seg.values()) * 1e-3)}
 
 

@@ -90,7 +90,7 @@ EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s
            "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc",
            "i2s_comm_unique_id", "i2s_comm_create", "i2s_comm_destroy", "i2s_comm_last_error", "i2s_comm_shard", "i2s_comm_all",
            "i2s_set_board_sink", "i2s_allgather_boards",
-           "i2s_set_profiling", "i2s_last_kernel_timing", "i2s_kernel_timing_name", "i2s_blur_band_stats"]
+           "i2s_set_profiling", "i2s_last_kernel_timing", "i2s_kernel_timing_name", "i2s_blur_band_stats", "i2s_hysteresis_stats"]
 NSEG = 14
 ABI_VERSION = 2
 COMM_ID_BYTES = 128
@@ -163,6 +163,7 @@ class I2sLibrary:
         L.i2s_allgather_boards.argtypes = [vp, vp, vp, C.c_int, vp, vp]
         L.i2s_set_profiling.argtypes = [vp, C.c_int]
         L.i2s_blur_band_stats.argtypes = [vp, ip, ip]
+        L.i2s_hysteresis_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ip]
         L.i2s_last_kernel_timing.argtypes = [vp, f32p]
         L.i2s_kernel_timing_name.argtypes = [C.c_int]
         L.i2s_kernel_timing_name.restype = C.c_char_p

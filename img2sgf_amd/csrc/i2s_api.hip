@@ -111,6 +111,8 @@ struct i2s_ctx {
     int debug = 0;
     bool hy_no_tail = false;        // a grid barrier of k_hysteresis_tail timed out once (a shared GPU): plain launches only from then on
     int hyst_k[2] = {1, 1};         // plain hysteresis launches per phase in front of the persistent tail: what the last call needed
+    long long n_passes = 0, n_redone = 0;      // device passes run since i2s_create / of those, passes run again because a phase had not converged
+    int hyst_used_max[2] = {0, 0};  // most hysteresis passes a phase has needed so far (plain launches + what the tail added)
     int last_nb = 0;
     HoughTrig last_trig{};
     float timing[5] = {0, 0, 0, 0, 0};
@@ -652,8 +654,10 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         I2S_HIP(hipStreamSynchronize(st));
         I2S_HIP(hipGetLastError());
         bool converged = true;
+        ctx->n_passes++;
         for (int ph = 0; ph < 2; ph++) {
             const int used = ctx->h_flags[ph];                              // passes the phase needed, -1: budget or barrier timeout
+            if (used > ctx->hyst_used_max[ph]) ctx->hyst_used_max[ph] = used;
             if (used < 0) {
                 converged = false;
                 if (used == -2) ctx->hy_no_tail = true;                     // no second second-long timeout on this context
@@ -666,6 +670,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
         }
         if (converged) break;
         // hysteresis had not reached its fixed point: redo this device pass with more plain launches
+        ctx->n_redone++;
     }
     for (int i = 0; i < nb; i++) boards[dst[i]] = ctx->h_boards[i];
     if (full) {
@@ -1049,6 +1054,14 @@ extern "C" int i2s_blur_band_stats(i2s_ctx* ctx, int* flagged, int* total)
             for (int x = 0; x < bx; x++) { nt++; nf += f[((size_t)b * nby + y) * nbx + x] != 0; }
     }
     *flagged = nf; *total = nt;
+    return I2S_OK;
+}
+
+extern "C" int i2s_hysteresis_stats(const i2s_ctx* ctx, long long* passes, long long* redone, int used_max[2])
+{
+    if (!ctx || !passes || !redone || !used_max) return I2S_E_INVALID;
+    *passes = ctx->n_passes; *redone = ctx->n_redone;
+    used_max[0] = ctx->hyst_used_max[0]; used_max[1] = ctx->hyst_used_max[1];
     return I2S_OK;
 }
 

@@ -438,6 +438,13 @@ class Detector:
         self._check(self.lib.dll.i2s_blur_band_stats(self._ctx, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def hysteresis_stats(self):
+        """dict(passes, redone, used_max): device passes since the context was created, how many of them had to be run again because
+        Canny's hysteresis had not converged, and the most propagation passes (main Canny, HoughCircles) a device pass has needed."""
+        n, r, k = C.c_longlong(), C.c_longlong(), (C.c_int * 2)()
+        self._check(self.lib.dll.i2s_hysteresis_stats(self._ctx, C.byref(n), C.byref(r), k))
+        return dict(passes=n.value, redone=r.value, used_max=[k[0], k[1]])
+
     def last_kernel_timing(self):
         """{kernel group: ms} of the last detect call, in launch order (profiling must be on)."""
         ms = (C.c_float * _lib.NSEG)()

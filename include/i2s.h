@@ -331,6 +331,10 @@ const char* i2s_kernel_timing_name(int i);
 /* The blur bank's two-valued speculation (k_blur) on the last device pass: of the `total` 256 x 64-pixel bands of its images, `flagged`
  * held a pixel that is neither 0 nor 255 and went through the general kernels (Gaussians + sorting network + bit-sliced medians). */
 int  i2s_blur_band_stats(i2s_ctx* ctx, int* flagged, int* total);
+/* Canny hysteresis (cv.Canny's stack walk, img2sgf.py:162 and inside cv.HoughCircles :180) since i2s_create: `passes` device passes were
+ * run, `redone` of them a second time because a phase's persistent tail gave up (pass budget or grid-barrier timeout) before the
+ * fixed point; used_max[0 / 1] = the most propagation passes the main Canny's map / HoughCircles' maps have needed in one device pass. */
+int  i2s_hysteresis_stats(const i2s_ctx* ctx, long long* passes, long long* redone, int used_max[2]);
 
 /* Debug/test hooks (not part of the drop-in surface): Hough-circle accumulator of variant v
  * ((h)x(w) int32, cell layout = pixel layout) and line accumulators. Enabled by

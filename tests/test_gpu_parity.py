@@ -111,6 +111,10 @@ def test_all_reference_images_one_mixed_batch(sw):
     for n, img, b in zip(IMAGES, imgs, boards):
         ref = opipe.process_image(img, keep_planes=False, compat=switches.compat(sw))
         assert board_to_sgf(b) == ref["sgf"], (n, sw)
+    # the reference's own scans never make the host run a device pass again (the persistent tail finishes their hysteresis): 18 images
+    # in passes of 6; what the phases needed is reported
+    hy = det.hysteresis_stats()
+    assert hy["passes"] == 3 and hy["redone"] == 0 and min(hy["used_max"]) >= 1, hy
     det.close()
 
 
