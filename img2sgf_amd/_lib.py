@@ -13,7 +13,7 @@ BOARD_SIZE = 19
 NSLOTS = 10
 MAX_CIRCLES = 16384
 MAX_LINES = 1024
-MAX_CENTRES = 256
+MAX_CENTRES = 1024
 PLANE_NAMES = {"grey": 0, "edges": 1, "median3": 2, "gauss3": 3, "median5": 4, "gauss5": 5, "median7": 6,
                "gauss7": 7, "removed": 8, "canny_map": 9}
 
@@ -82,7 +82,7 @@ class I2sXform(C.Structure):
 
 
 assert C.sizeof(I2sBoard) == 384
-assert C.sizeof(I2sResult) == 73384 + (16384 - 4096) * 13
+assert C.sizeof(I2sResult) == 73384 + (16384 - 4096) * 13 + 4 * (1024 - 256) * 8
 
 EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
            "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_jpeg_info", "i2s_detect_jpeg_batch", "i2s_jpeg_last_rounds", "i2s_jpeg_last_handed_back", "i2s_jpeg_set_max_rounds", "i2s_jpeg_last_timing",
@@ -92,7 +92,7 @@ EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s
            "i2s_set_board_sink", "i2s_allgather_boards",
            "i2s_set_profiling", "i2s_last_kernel_timing", "i2s_kernel_timing_name", "i2s_blur_band_stats", "i2s_hysteresis_stats"]
 NSEG = 14
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 
 

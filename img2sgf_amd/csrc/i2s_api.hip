@@ -674,7 +674,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
     }
     for (int i = 0; i < nb; i++) boards[dst[i]] = ctx->h_boards[i];
     if (full) {
-        // The full record is 233 KB, nearly all of it the circle arrays' capacity: only what is in use crosses the bus -- the part
+        // The full record is 258 KB, nearly all of it the circle arrays' capacity: only what is in use crosses the bus -- the part
         // in front of the circles, n_circles circles, n_circles kept flags, the two boards behind them (the board record, already
         // on the host, says how many circles there are).  Array entries beyond the counts are left as the caller had them.
         // The used parts are packed on the device and come over in one copy into pinned memory (three copies per image

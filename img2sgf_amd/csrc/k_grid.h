@@ -125,6 +125,7 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
                                               GridParams gp, int do_cluster, i2s_result* __restrict__ res,
                                               i2s_board* __restrict__ boards)
 {
+    static_assert(I2S_MAX_CENTRES >= I2S_MAX_LINES, "every cluster holds a line: the centres cannot overflow before the lines do");
     __shared__ float s_sorted[I2S_MAX_LINES];
     __shared__ double s_tmp[2][I2S_MAX_CENTRES + 4];
     __shared__ double s_cen[2][I2S_MAX_CENTRES];      // hcentres / vcentres

@@ -47,13 +47,14 @@
 extern "C" {
 #endif
 
-#define I2S_ABI_VERSION 2
+#define I2S_ABI_VERSION 3
 
 #define I2S_BOARD_SIZE 19      /* img2sgf.py:43 */
 #define I2S_NSLOTS 10          /* blur-bank slots, img2sgf.py:171-175 */
 #define I2S_MAX_CIRCLES 16384  /* concatenated circles per image (all 10 slots) */
 #define I2S_MAX_LINES 1024     /* Hough-line peaks per direction */
-#define I2S_MAX_CENTRES 256    /* cluster centres / completed grid lines per direction */
+#define I2S_MAX_CENTRES 1024   /* cluster centres / completed grid lines per direction: = I2S_MAX_LINES (a cluster holds at least one
+                                  line), so the reference's unbounded lists of centres are never cut short on their own account */
 
 /* return codes */
 enum {
@@ -159,7 +160,7 @@ typedef struct i2s_board {
 
 /* Full per-image record: every value the reference leaves in its globals for the GUI.  Array entries beyond their counts
  * (circles[n_circles ..], circle_kept[n_circles ..], hlines[n_hlines ..] ...) are unspecified: a detect call copies only the
- * used part of the circle arrays to the host (the record's capacity is 233 KB, a diagram uses about 20). */
+ * used part of the circle arrays to the host (the record's capacity is 258 KB, a diagram uses about 45). */
 typedef struct i2s_result {
     int32_t status;
     int32_t line_threshold;

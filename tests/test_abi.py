@@ -28,7 +28,7 @@ def test_struct_sizes_and_defaults(lib):
     lib.dll.i2s_default_params(C.byref(p))
     assert (p.canny_lo, p.canny_hi, p.hc_param1, p.hc_param2, p.hc_min_radius, p.hc_max_radius) == (50, 200, 100, 30, 1, 30)
     assert (p.black_threshold, p.align_x, p.align_y, p.min_grid_spacing, p.big_space_ratio) == (128, 2, 0, 10.0, 1.6)
-    assert lib.dll.i2s_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.dll.i2s_abi_version() == _lib.ABI_VERSION == 3
     assert lib.dll.i2s_choose_threshold(750, 747) == 74 and lib.dll.i2s_choose_threshold(1024, 1024) == 96
     assert lib.dll.i2s_strerror(-2).decode().startswith("no HIP device")
 

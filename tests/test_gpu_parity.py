@@ -355,6 +355,34 @@ def test_large_images():
     det.close()
 
 
+def test_phone_photo_and_extreme_aspect_sizes():
+    """Maximum sizes: a 12-megapixel colour image (4032 x 3024, what a phone hands the reference when a user photographs a diagram:
+    a mosaic of the reference's largest scan and a synthetic diagram, so coordinates beyond 4095 carry circles, lines and stones)
+    and the two extreme aspect ratios a context allows (16384 wide / 16384 tall strips holding a row / column of diagrams' crops):
+    coordinates up to 16383 in every packed field (edge records, centre lists, sort keys, erase boxes, rho rows).  Every plane,
+    circle, line and record against the oracle."""
+    scan = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", "ex16.jpg"))         # 1265 x 1245 RGB
+    diag = synth.synth_diagram(21)[0]
+    photo = np.full((3024, 4032, 3), 255, np.uint8)
+    for k, (y, x) in enumerate([(0, 0), (1500, 2600), (1700, 100)]):
+        photo[y:y + scan.shape[0], x:x + scan.shape[1]] = scan if k != 1 else scan[::-1, ::-1]
+    for y, x in [(100, 1400), (1990, 1500), (1990, 3000)]:
+        photo[y:y + 1024, x:x + 1024] = diag[:, :, None]
+    det = Detector(0, 1, 4032, 3024)
+    parity.run_and_compare(det, [photo])
+    det.close()
+    strip = np.full((200, 16384), 255, np.uint8)
+    for k in range(16):
+        strip[:, k * 1024:(k + 1) * 1024] = synth.synth_diagram(30 + k)[0][300:500]
+    strip[:, 16380:] = 0
+    det = Detector(0, 1, 16384, 200)
+    parity.run_and_compare(det, [strip])
+    det.close()
+    det = Detector(0, 1, 200, 16384)
+    parity.run_and_compare(det, [np.ascontiguousarray(strip.T)])
+    det.close()
+
+
 def test_capacity_grows_with_the_context_area():
     """4096 small rings on a 16-pixel pitch: two of the ten HoughCircles calls return ~3840 circles each, 7690 in all -- more
     than round 1's fixed lists (2048 per call, 4096 per image) could hold.  The reference's lists are unbounded
