@@ -279,6 +279,8 @@ static int create_impl(i2s_ctx* ctx)
 
 extern "C" int i2s_create(i2s_ctx** out, int device_id, int max_batch, int max_w, int max_h)
 {
+    // (k_vote_centres packs "record index inside a pair of HoughCircles inputs | direction << 31" into one dword)
+    static_assert(2ll * ((16384 + EB - 1) / EB) * ((16384 + EB - 1) / EB) * EB_CAP < (1ll << 31), "vote items: 31-bit record index");
     if (!out || device_id < 0 || max_batch < 1 || max_batch > 4096 || max_w < 1 || max_h < 1 || max_w > 16384 || max_h > 16384)
         return I2S_E_INVALID;
     i2s_ctx* ctx = new i2s_ctx();

@@ -161,7 +161,10 @@ __global__ __launch_bounds__(EBT) void k_edge_bins(const ImgDesc* __restrict__ d
     }
 }
 
-// Votes of up to 64 (edge record, direction) items, one per lane (item = index into bin_ent | direction << 31).
+// Votes of up to 64 (edge record, direction) items, one per lane (item = index into `bin_ent` | direction << 31, where `bin_ent` is the
+// record array of the workgroup's PAIR of HoughCircles inputs: 2 x bins x EB_CAP <= 2^29 records for the largest context, so the index
+// never reaches the direction bit.  Until the end of round 4 the index counted from the start of the whole context's array and passed
+// 2^31 from image 256 of a pass of 1024 x 1024 images on -- wrong boards for the images behind it, found by a pass of 320).
 // The lane walks its item through r = min_r .. max_r: cell = ((x * 1024 + r * sx) >> 10, (y * 1024 + r * sy) >> 10), relative to
 // the first valid cell of the tile, with (sx, sy) negated for the second direction.  Cells outside [0, vx_n) x [0, vy_n)
 // (outside the image or the tile) are skipped, which equals OpenCV's "break at the first cell outside the image" because a
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(VPT) void k_vote_centres(const ImgDesc* __restrict_
     const int offx = vx_lo - lx0, offy = vy_lo - ly0;      // valid-cell origin inside the LDS tile (0 or 1)
     const int nsteps = max_r - min_r + 1;          // <= 31
     const int lane = tid & 63, wave = tid >> 6;
-    const unsigned ent_split = (unsigned)((size_t)(bv + 1) * g.bins * EB_CAP);     // first record index of variant 2p + 1
+    bin_ent += (size_t)bv * g.bins * EB_CAP;          // records of this pair of inputs; bin_of / items / the walk index from here
+    const unsigned ent_split = (unsigned)g.bins * (unsigned)EB_CAP;                // first record index of variant 2p + 1
     const int xl = (int)((vx_n + (unsigned)offx) << 10), yl = (int)((vy_n + (unsigned)offy) << 10);
     // one wavefront per bin: a coalesced 512-byte load brings 64 edge records, every lane tests whether ITS record's rays can touch
     // the tile at all, the surviving (record, direction) items are compacted into the wavefront's LDS ring, and whenever 64 are
@@ -270,9 +274,9 @@ __global__ __launch_bounds__(VPT) void k_vote_centres(const ImgDesc* __restrict_
     // flight ahead of the one it culls.
     int my_cnt_a = 0, my_cnt_b = 0, my_bin = 0;
     if (lane < nbin) {
-        my_bin = (int)((size_t)bv * g.bins + (size_t)(by0 + lane / nbx) * g.bw + (bx0 + lane % nbx));
-        my_cnt_a = bin_cnt[my_bin];
-        my_cnt_b = bin_cnt[my_bin + g.bins];
+        my_bin = (by0 + lane / nbx) * g.bw + (bx0 + lane % nbx);                // relative to the pair's first bin
+        my_cnt_a = bin_cnt[(size_t)bv * g.bins + my_bin];
+        my_cnt_b = bin_cnt[(size_t)(bv + 1) * g.bins + my_bin];
     }
     auto bin_of = [&](int q, int& n, const uint2*& ent) {      // q is wave-uniform
         const int qq = q < nbin ? q : q - nbin;

@@ -383,6 +383,28 @@ def test_phone_photo_and_extreme_aspect_sizes():
     det.close()
 
 
+def test_record_indices_beyond_2_to_31():
+    """A context whose edge-record array holds more than 2^31 records (max_batch x 8 inputs x bins x 1024: 72 images of up to
+    2048 x 2048 here; 320 images of 1024 x 1024 is the same): k_vote_centres packs a record index and the ray's direction into one
+    dword, and until the end of round 4 that index counted from the start of the whole array -- images whose records lay beyond 2^31
+    (from image 64 of this context on) silently got wrong accumulators and wrong boards.  The index is now relative to the workgroup's
+    pair of inputs.  Small diagrams in the large context against a small context (itself checked against the oracle elsewhere) and
+    against the generator."""
+    seeds = range(72)
+    imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in seeds]
+    big = Detector(0, 72, 2048, 2048)
+    small = Detector(0, 8, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    a = big.detect_batch(imgs, full=False)
+    b = small.detect_batch(imgs, full=False)
+    for k in range(len(imgs)):
+        assert bytes(a[k]) == bytes(b[k]), k
+    for name in ("removed", "edges"):
+        np.testing.assert_array_equal(big.fetch_plane(71, name), small.fetch_plane(7, name))
+    ref = opipe.process_image(imgs[71])
+    assert board_to_sgf(a[71]) == ref["sgf"]
+    big.close(); small.close()
+
+
 def test_capacity_grows_with_the_context_area():
     """4096 small rings on a 16-pixel pitch: two of the ten HoughCircles calls return ~3840 circles each, 7690 in all -- more
     than round 1's fixed lists (2048 per call, 4096 per image) could hold.  The reference's lists are unbounded
