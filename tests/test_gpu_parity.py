@@ -405,6 +405,30 @@ def test_record_indices_beyond_2_to_31():
     big.close(); small.close()
 
 
+def test_largest_batch_and_largest_geometry():
+    """The two ends of what i2s_create accepts: 4096 images in ONE device pass (tiny ragged grey / two-valued / colour images) and a
+    16384 x 16384 context (262 144 edge bins and 131 072 hysteresis tiles per plane) holding ordinary images -- records byte for byte
+    as from small contexts, one image of each against the oracle."""
+    rng = np.random.default_rng(5)
+    imgs = []
+    for k in range(4096):
+        h, w = int(rng.integers(1, 64)), int(rng.integers(1, 64))
+        imgs.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if k % 3 == 0 else
+                    np.where(rng.random((h, w)) < 0.5, 0, 255).astype(np.uint8) if k % 3 == 1 else rng.integers(0, 256, (h, w), dtype=np.uint8))
+    big = Detector(0, 4096, 64, 64)
+    small = Detector(0, 16, 64, 64)
+    a = big.detect_batch(imgs, full=False)
+    b = small.detect_batch(imgs, full=False)
+    assert [bytes(x) for x in a] == [bytes(x) for x in b]
+    big.close()
+    parity.run_and_compare(small, imgs[4090:4096])
+    small.close()
+    huge = Detector(0, 1, 16384, 16384)
+    for im in (synth.synth_diagram(3, geom=synth.GEOM_SMALL)[0], opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", "ex9.jpg"))):
+        parity.run_and_compare(huge, [im])
+    huge.close()
+
+
 def test_capacity_grows_with_the_context_area():
     """4096 small rings on a 16-pixel pitch: two of the ten HoughCircles calls return ~3840 circles each, 7690 in all -- more
     than round 1's fixed lists (2048 per call, 4096 per image) could hold.  The reference's lists are unbounded
