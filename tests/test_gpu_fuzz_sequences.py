@@ -39,6 +39,16 @@ def test_fuzz_call_sequences_on_one_context(seed):
             dets = parity.run_and_compare(det, [imgs[k] for k in keep], params=params, internals=internals, oracle_kwargs=okw)
             for k, d in zip(keep, dets):
                 assert d.board_ready == (boards[k].status == 0), (seed, call, k)
+            if rng.random() < 0.5:
+                # apply_black_thresh (img2sgf.py:762-766): identify_board alone on the images of the last device pass, twice
+                kept = [imgs[k] for k in keep]
+                nb_last = (len(kept) - 1) % det.max_batch + 1
+                for _ in range(2):
+                    thr, al = int(rng.integers(0, 256)), (2 + int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+                    params.black_threshold, params.alignment = thr, al
+                    again = det.classify(0, nb_last, params)
+                    for q, d in enumerate(again):
+                        parity.compare_detection(d, opipe.process_image(kept[len(kept) - nb_last + q], **dict(okw, black_thr=thr, alignment=al)))
         else:
             for k in keep:
                 ref = opipe.process_image(imgs[k], **okw)
