@@ -86,3 +86,64 @@ def run_and_compare(det, images, params=None, internals=False, oracle_kwargs=Non
                 compare_hough_internals(det, k - first_last, ref)
         compare_detection(d, ref)
     return dets
+
+
+def check_validate_grid_capacity(det, trials):
+    """i2s_validate_grid (img2sgf.py:420-445) on 0, 1, 2 ... 1024 centres per direction -- the record's capacity, which is the line
+    capacity -- uniform, with missing lines, closer than min_grid_spacing, with jitter: the reference's eight outputs, exactly."""
+    from img2sgf_amd import pipeline
+    from img2sgf_amd.pipeline import Params
+    from oracle import glue
+    rng = np.random.default_rng(3)
+
+    def centres(n):
+        if n == 0:
+            return np.zeros(0)
+        sp = rng.choice([3.0, 9.99, 10.0, 12.5, 30.0])
+        return np.cumsum(np.full(n, sp) + (rng.random(n) < 0.15) * sp * rng.integers(1, 4, n) + rng.random(n) * rng.choice([0, 0.5, 3]))
+
+    for trial in range(trials):
+        hc = centres(int(rng.choice([0, 1, 2, 5, 19, 20, 21, 22, 40, 300, 1024])))
+        vc = centres(int(rng.choice([0, 1, 2, 19, 21, 23, 257, 1000, 1024])))
+        circles = np.stack([rng.uniform(0, 600, 30), rng.uniform(0, 600, 30), rng.uniform(1, 40, 30)], 1).astype(np.float32)
+        got = pipeline.validate_grid(hc, vc, circles, Params(), det)
+        want = glue.validate_grid(hc, vc, circles)
+        assert bool(got[0]) == bool(want["valid"]), trial
+        if want["valid"]:
+            assert (got[2], got[3], got[6], got[7]) == (want["vsize"], want["hsize"], want["hspace"], want["vspace"]), trial
+            np.testing.assert_array_equal(got[4], want["hc"])
+            np.testing.assert_array_equal(got[5], want["vc"])
+            np.testing.assert_array_equal(np.asarray(got[1], np.float32).reshape(-1, 3), np.asarray(want["circles"], np.float32).reshape(-1, 3))
+
+
+def check_find_lines_degenerate(det, size):
+    """find_all_lines (img2sgf.py:230-265, three cv.HoughLines calls) on injected images at the edges: all white (every pixel votes),
+    all black, one pixel, stripes of period 2 .. 11 in both directions (hundreds of peaks), a checkerboard, a grid, noise, 1 x N and
+    N x 1 images, grey values other than 0 / 255 (any non-zero pixel votes) -- thresholds from 1 vote up: the rho lists in the
+    reference's output order, exactly; a direction with more than I2S_MAX_LINES peaks must be refused, not cut.  size = the largest side."""
+    from img2sgf_amd import pipeline
+    from img2sgf_amd.pipeline import I2sError, Params
+    from oracle import glue
+    rng = np.random.default_rng(4)
+    s = size
+    cases = [np.full((3 * s // 7, 4 * s // 7), 255, np.uint8), np.zeros((3 * s // 7, 4 * s // 7), np.uint8),
+             np.pad(np.full((1, 1), 255, np.uint8), ((s // 7, s // 14), (s // 35, 3 * s // 7)))]
+    for per in (2, 3, 5, 9, 11):
+        a = np.zeros((s, s - 10), np.uint8)
+        a[::per] = 255
+        cases += [a, np.ascontiguousarray(a.T[:s - 50])]
+    cases += [((np.indices((s // 2 - 17, 4 * s // 7 + 1)).sum(0) % 2) * 255).astype(np.uint8),
+              np.maximum(*[(np.indices((6 * s // 7, 6 * s // 7))[k] % 31 == 0) * 255 for k in (0, 1)]).astype(np.uint8),
+              (rng.random((5 * s // 7, 9 * s // 10)) < 0.1).astype(np.uint8) * 255, np.full((1, s), 255, np.uint8), np.full((s, 1), 255, np.uint8),
+              rng.integers(0, 256, (2 * s // 7, 3 * s // 7), dtype=np.uint8)]
+    flat = lambda a: np.asarray(a, np.float32).reshape(-1)
+    for n, im in enumerate(cases):
+        for thr in (1, 2, 20, 74, 300):
+            want_h, want_v = glue.find_lines(im, thr, True), glue.find_lines(im, thr, False)
+            try:
+                got_h, got_v = pipeline.find_all_lines(im, thr, Params(), det)
+            except I2sError:
+                assert len(want_h) > 1024 or len(want_v) > 1024, (n, thr)
+                continue
+            np.testing.assert_array_equal(flat(got_h), flat(want_h), err_msg="case %d threshold %d" % (n, thr))
+            np.testing.assert_array_equal(flat(got_v), flat(want_v), err_msg="case %d threshold %d" % (n, thr))

@@ -373,3 +373,15 @@ def test_hysteresis_chain_through_many_tiles(lib):
     parity.run_and_compare(det, [img], internals=False)
     parity.run_and_compare(det, [img], internals=False)
     det.close()
+
+
+def test_validate_grid_from_none_to_1024_centres_emulated(lib):
+    det = Detector(0, 1, 600, 600, lib=lib)
+    parity.check_validate_grid_capacity(det, 60)
+    det.close()
+
+
+def test_find_lines_on_degenerate_images_emulated(lib):
+    det = Detector(0, 1, 140, 140, lib=lib)
+    parity.check_find_lines_degenerate(det, 140)
+    det.close()

@@ -430,63 +430,14 @@ def test_largest_batch_and_largest_geometry():
 
 
 def test_validate_grid_from_none_to_1024_centres():
-    """i2s_validate_grid (img2sgf.py:420-445) on 0, 1, 2 ... 1024 centres per direction -- the record's capacity, which is the line
-    capacity -- uniform, with missing lines, closer than min_grid_spacing, with jitter: the reference's eight outputs, exactly."""
-    from img2sgf_amd import pipeline
-    from oracle import glue
     det = Detector(0, 1, 600, 600)
-    rng = np.random.default_rng(3)
-
-    def centres(n):
-        if n == 0:
-            return np.zeros(0)
-        sp = rng.choice([3.0, 9.99, 10.0, 12.5, 30.0])
-        return np.cumsum(np.full(n, sp) + (rng.random(n) < 0.15) * sp * rng.integers(1, 4, n) + rng.random(n) * rng.choice([0, 0.5, 3]))
-
-    for trial in range(300):
-        hc = centres(int(rng.choice([0, 1, 2, 5, 19, 20, 21, 22, 40, 300, 1024])))
-        vc = centres(int(rng.choice([0, 1, 2, 19, 21, 23, 257, 1000, 1024])))
-        circles = np.stack([rng.uniform(0, 600, 30), rng.uniform(0, 600, 30), rng.uniform(1, 40, 30)], 1).astype(np.float32)
-        got = pipeline.validate_grid(hc, vc, circles, Params(), det)
-        want = glue.validate_grid(hc, vc, circles)
-        assert bool(got[0]) == bool(want["valid"]), trial
-        if want["valid"]:
-            assert (got[2], got[3], got[6], got[7]) == (want["vsize"], want["hsize"], want["hspace"], want["vspace"]), trial
-            np.testing.assert_array_equal(got[4], want["hc"]); np.testing.assert_array_equal(got[5], want["vc"])
-            np.testing.assert_array_equal(np.asarray(got[1], np.float32).reshape(-1, 3), np.asarray(want["circles"], np.float32).reshape(-1, 3))
+    parity.check_validate_grid_capacity(det, 300)
     det.close()
 
 
 def test_find_lines_on_degenerate_images():
-    """find_all_lines (img2sgf.py:230-265, three cv.HoughLines calls) on injected images at the edges: all white (every pixel votes),
-    all black, one pixel, stripes of period 2 .. 11 in both directions (hundreds of peaks), a checkerboard, a grid, noise, 1 x N and
-    N x 1 images, grey values other than 0 / 255 (any non-zero pixel votes) -- thresholds from 1 vote up: the rho lists in the
-    reference's output order, exactly; a direction with more than I2S_MAX_LINES peaks must be refused, not cut."""
-    from img2sgf_amd import pipeline
-    from img2sgf_amd.pipeline import I2sError
-    from oracle import glue
-    rng = np.random.default_rng(4)
-    cases = [np.full((300, 400), 255, np.uint8), np.zeros((300, 400), np.uint8), np.pad(np.full((1, 1), 255, np.uint8), ((100, 50), (20, 300)))]
-    for per in (2, 3, 5, 9, 11):
-        a = np.zeros((700, 690), np.uint8)
-        a[::per] = 255
-        cases += [a, np.ascontiguousarray(a.T[:650])]
-    cases += [((np.indices((333, 401)).sum(0) % 2) * 255).astype(np.uint8),
-              np.maximum(*[(np.indices((600, 600))[k] % 31 == 0) * 255 for k in (0, 1)]).astype(np.uint8),
-              (rng.random((500, 640)) < 0.1).astype(np.uint8) * 255, np.full((1, 700), 255, np.uint8), np.full((700, 1), 255, np.uint8),
-              rng.integers(0, 256, (200, 300), dtype=np.uint8)]
     det = Detector(0, 1, 700, 700)
-    flat = lambda a: np.asarray(a, np.float32).reshape(-1)
-    for n, im in enumerate(cases):
-        for thr in (1, 2, 20, 74, 300):
-            want_h, want_v = glue.find_lines(im, thr, True), glue.find_lines(im, thr, False)
-            try:
-                got_h, got_v = pipeline.find_all_lines(im, thr, Params(), det)
-            except I2sError:
-                assert len(want_h) > 1024 or len(want_v) > 1024, (n, thr)
-                continue
-            np.testing.assert_array_equal(flat(got_h), flat(want_h), err_msg="case %d threshold %d" % (n, thr))
-            np.testing.assert_array_equal(flat(got_v), flat(want_v), err_msg="case %d threshold %d" % (n, thr))
+    parity.check_find_lines_degenerate(det, 700)
     det.close()
 
 
