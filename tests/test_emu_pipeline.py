@@ -385,3 +385,13 @@ def test_find_lines_on_degenerate_images_emulated(lib):
     det = Detector(0, 1, 140, 140, lib=lib)
     parity.check_find_lines_degenerate(det, 140)
     det.close()
+
+
+def test_call_sequence_on_one_context_emulated(lib):
+    """The emulated twin of tests/test_gpu_fuzz_sequences.py (state that leaks from one call into the next lives in the host code,
+    which the emulated build shares): one context, six calls of 1 .. 4 images of at most 88 pixels a side."""
+    from test_gpu_fuzz_sequences import run_call_sequence
+    rng = np.random.default_rng(70001)
+    det = Detector(0, 2, 88, 88, lib=lib)
+    run_call_sequence(det, rng, "emu", n_calls=6, side=88, max_images=4)
+    det.close()

@@ -20,12 +20,10 @@ pytestmark = pytest.mark.gpu
 N_SEEDS = int(os.environ.get("I2S_FUZZ_SEQ_SEEDS", 12))
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_fuzz_call_sequences_on_one_context(seed):
-    rng = np.random.default_rng(70000 + seed)
-    det = Detector(0, int(rng.integers(1, 5)), 330, 330)
-    for call in range(10):
-        imgs = [np.ascontiguousarray(_random_image(rng)[:330, :330]) for _ in range(int(rng.integers(1, 10)))]
+def run_call_sequence(det, rng, tag, n_calls=10, side=330, max_images=9):
+    """The sequence itself (also driven by the emulated twin in test_emu_pipeline.py, on small images)."""
+    for call in range(n_calls):
+        imgs = [np.ascontiguousarray(_random_image(rng)[:side, :side]) for _ in range(int(rng.integers(1, max_images + 1)))]
         params, okw = _extreme_params(rng) if rng.random() < 0.2 else _random_params(rng, int(rng.integers(0, 1000)))
         params.schedule = bool(rng.random() < 0.4)
         det.set_profiling(bool(rng.random() < 0.3))
@@ -38,7 +36,7 @@ def test_fuzz_call_sequences_on_one_context(seed):
             params.schedule = False                     # (run_and_compare reads the planes of the LAST pass in input order)
             dets = parity.run_and_compare(det, [imgs[k] for k in keep], params=params, internals=internals, oracle_kwargs=okw)
             for k, d in zip(keep, dets):
-                assert d.board_ready == (boards[k].status == 0), (seed, call, k)
+                assert d.board_ready == (boards[k].status == 0), (tag, call, k)
             if rng.random() < 0.5:
                 # apply_black_thresh (img2sgf.py:762-766): identify_board alone on the images of the last device pass, twice
                 kept = [imgs[k] for k in keep]
@@ -52,5 +50,12 @@ def test_fuzz_call_sequences_on_one_context(seed):
         else:
             for k in keep:
                 ref = opipe.process_image(imgs[k], **okw)
-                assert (board_to_sgf(boards[k]) if boards[k].status == 0 else None) == ref["sgf"], (seed, call, k)
+                assert (board_to_sgf(boards[k]) if boards[k].status == 0 else None) == ref["sgf"], (tag, call, k)
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_call_sequences_on_one_context(seed):
+    rng = np.random.default_rng(70000 + seed)
+    det = Detector(0, int(rng.integers(1, 5)), 330, 330)
+    run_call_sequence(det, rng, seed)
     det.close()
