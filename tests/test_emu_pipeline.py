@@ -395,3 +395,10 @@ def test_call_sequence_on_one_context_emulated(lib):
     det = Detector(0, 2, 88, 88, lib=lib)
     run_call_sequence(det, rng, "emu", n_calls=6, side=88, max_images=4)
     det.close()
+
+
+@pytest.mark.parametrize("seed", [1, 4, 7, 12])
+def test_extreme_parameters_emulated(lib, seed):
+    """Emulated twin of tests/test_gpu_fuzz_extreme.py: the edges of the parameter envelope on images of at most 64 x 44 pixels."""
+    from test_gpu_fuzz_extreme import run_extreme_seed
+    run_extreme_seed(lambda nb, w, h: Detector(0, nb, w, h, lib=lib), seed, side=64, n_images=2)

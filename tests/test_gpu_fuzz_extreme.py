@@ -33,15 +33,12 @@ def _extreme_params(rng):
     return p, dict(canny=(lo, hi), hc=hc, threshold=thr, black_thr=black, alignment=align)
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_fuzz_extreme_parameters(seed):
+def run_extreme_seed(make_detector, seed, side=160, n_images=3):
+    """One seed (also driven by the emulated twin in test_emu_pipeline.py, on smaller images)."""
     rng = np.random.default_rng(9000 + seed)
-    imgs = []
-    for _ in range(3):
-        im = _random_image(rng)
-        imgs.append(np.ascontiguousarray(im[:140, :160]))
+    imgs = [np.ascontiguousarray(_random_image(rng)[:side - 20, :side]) for _ in range(n_images)]
     params, okw = _extreme_params(rng)
-    det = Detector(0, 3, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    det = make_detector(n_images, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
     dets = det.detect_batch(imgs, params, full=True)
     over = [k for k, d in enumerate(dets) if d.status == 100]
     for k in over:
@@ -54,3 +51,8 @@ def test_fuzz_extreme_parameters(seed):
     if imgs:
         parity.run_and_compare(det, imgs, params=params, oracle_kwargs=okw)
     det.close()
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_extreme_parameters(seed):
+    run_extreme_seed(lambda nb, w, h: Detector(0, nb, w, h), seed)
