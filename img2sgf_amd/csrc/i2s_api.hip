@@ -361,11 +361,13 @@ static int hough_trig(const i2s_params* p, HoughTrig* t)
 
 // The used parts of the full records of a pass, packed: per image [the record up to `circles` + n_circles circles][n_circles kept flags,
 // padded to 4][detected + board], at byte offset off[i] of `out` (run_pass computes the offsets from the board records it already has).
-__global__ __launch_bounds__(256) void k_pack_results(const i2s_result* __restrict__ res, const unsigned long long* __restrict__ off,
-                                                      uint8_t* __restrict__ out)
+__global__ __launch_bounds__(256) void k_pack_results(const i2s_result* __restrict__ res, const i2s_board* __restrict__ boards,
+                                                      const unsigned long long* __restrict__ off, uint8_t* __restrict__ out)
 {
     const i2s_result* r = res + blockIdx.x;
-    const unsigned n = (unsigned)r->n_circles;
+    // n comes from the BOARD record: the host lays the offsets out and unpacks from its copy of that record (a capacity
+    // overflow of the line peaks left the two counts different, and the record of n_circles circles overran its slot)
+    const unsigned n = (unsigned)boards[blockIdx.x].n_circles;
     const unsigned* s32 = reinterpret_cast<const unsigned*>(r);
     unsigned* d32 = reinterpret_cast<unsigned*>(out + off[blockIdx.x]);
     const unsigned head = (unsigned)(offsetof(i2s_result, circles) / 4) + n * 3, kept = (n + 3) / 4;
@@ -703,7 +705,7 @@ static int run_pass(i2s_ctx* ctx, int nb, int wmax, int hmax, bool has_c1, bool 
             ctx->pack_cap = want;
         }
         I2S_HIP(hipMemcpyAsync(ctx->d_pack_off, ctx->h_pack_off, nb * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_pack_results, dim3(nb), dim3(256), 0, st, ctx->d_res, ctx->d_pack_off, ctx->d_pack);
+        hipLaunchKernelGGL(k_pack_results, dim3(nb), dim3(256), 0, st, ctx->d_res, ctx->d_boards, ctx->d_pack_off, ctx->d_pack);
         I2S_HIP(hipGetLastError());
         I2S_HIP(hipMemcpyAsync(ctx->h_pack, ctx->d_pack, total, hipMemcpyDeviceToHost, st));
         I2S_HIP(hipStreamSynchronize(st));

@@ -141,11 +141,16 @@ __global__ __launch_bounds__(1024) void k_grid(const ImgDesc* __restrict__ desc,
     i2s_board* B = boards + b;
     const bool capacity = R->status == I2S_ST_CAPACITY;
     if (capacity) {
+        // nothing of an overflowed image is valid: the record says so in every count, and neither board keeps what an earlier pass
+        // left in this slot (the circle count too -- k_line_peaks' overflow leaves it standing, and the packed full record is laid
+        // out from the board record's count)
+        for (int i = tid; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i += GRID_THREADS) {
+            (&B->board[0][0])[i] = 0; (&R->board[0][0])[i] = 0; (&R->detected[0][0])[i] = 0;
+        }
         if (tid == 0) {
             R->found_grid = R->valid_grid = R->board_ready = 0; R->hsize = R->vsize = 0;
             R->n_hcentres = R->n_vcentres = R->n_hcomplete = R->n_vcomplete = 0;
-            R->n_stones = R->n_black = R->n_white = R->side_to_move = 0; R->n_circles_kept = 0;
-            for (int i = 0; i < I2S_BOARD_SIZE * I2S_BOARD_SIZE; i++) (&B->board[0][0])[i] = 0;
+            R->n_stones = R->n_black = R->n_white = R->side_to_move = 0; R->n_circles_kept = 0; R->n_circles = 0;
             B->status = I2S_ST_CAPACITY; B->side_to_move = 0; B->hsize = B->vsize = 0; B->found_grid = B->valid_grid = 0;
             B->n_black = B->n_white = 0; B->n_circles = 0; B->line_threshold = (uint16_t)R->line_threshold;
         }

@@ -147,3 +147,43 @@ def check_find_lines_degenerate(det, size):
                 continue
             np.testing.assert_array_equal(flat(got_h), flat(want_h), err_msg="case %d threshold %d" % (n, thr))
             np.testing.assert_array_equal(flat(got_v), flat(want_v), err_msg="case %d threshold %d" % (n, thr))
+
+
+def lines_overflow_image(seed=0, w=3000, h=160):
+    """A sparse-noise strip with four discs: at a Hough-line threshold of a few votes it has far more than I2S_MAX_LINES peaks in a
+    direction (status CAPACITY out of k_line_peaks) while HoughCircles has found circles on it -- ADVICE r4's reproduction."""
+    rng = np.random.default_rng(seed)
+    img = np.where(rng.random((h, w)) < 0.012, 0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[:h, :w]
+    for k in range(4):
+        img[(xx - (300 + 700 * k)) ** 2 + (yy - 80) ** 2 <= 20 ** 2] = 0
+    return img
+
+
+def check_capacity_by_lines_in_full_batch(det, diagrams, threshold=8):
+    """an image whose line peaks overflow (status CAPACITY, circles present) placed FIRST and LAST in a full=True
+    batch.  Its packed full record must not overrun its slot: the neighbours' records equal the oracle's, its own says "nothing
+    valid" in every count and carries no board of an earlier pass.  `diagrams`: images that detect normally."""
+    from img2sgf_amd.pipeline import Params, _detection_from_result
+    strip = lines_overflow_image()
+    diagrams = list(diagrams)
+    batch = [strip] + diagrams + [strip]
+    params = Params(line_threshold=threshold)
+    ref = opipe.process_image(strip, threshold=threshold, keep_planes=False)
+    assert len(ref["hlines"]) > 1024 or len(ref["vlines"]) > 1024, "the strip no longer overflows the line capacity"
+    assert len(ref["circles_all"]) > 0, "the strip must carry circles for this test to mean anything"
+    # an earlier pass leaves boards in every slot of the context
+    det.detect_batch((diagrams * len(batch))[:len(batch)], full=True)
+    imgs = [np.ascontiguousarray(im) for im in batch]
+    boards, res = det.detect_ptrs([im.ctypes.data for im in imgs], [im.shape[1] for im in imgs], [im.shape[0] for im in imgs],
+                                  [im.strides[0] for im in imgs], [1] * len(imgs), params, False, True)
+    for k in (0, len(batch) - 1):
+        r, b = res[k], boards[k]
+        assert r.status == 100 and b.status == 100 and not r.board_ready
+        assert r.n_circles == 0 and b.n_circles == 0 and r.n_circles_kept == 0 and r.n_stones == 0
+        assert r.n_hlines == 0 and r.n_vlines == 0
+        assert not np.ctypeslib.as_array(r.board).any() and not np.ctypeslib.as_array(r.detected).any()
+        assert not np.ctypeslib.as_array(b.board).any()
+        assert _detection_from_result(r).sgf is None
+    for k in range(1, len(batch) - 1):
+        compare_detection(_detection_from_result(res[k]), opipe.process_image(batch[k], threshold=threshold, keep_planes=False))

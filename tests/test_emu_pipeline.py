@@ -402,3 +402,11 @@ def test_extreme_parameters_emulated(lib, seed):
     """Emulated twin of tests/test_gpu_fuzz_extreme.py: the edges of the parameter envelope on images of at most 64 x 44 pixels."""
     from test_gpu_fuzz_extreme import run_extreme_seed
     run_extreme_seed(lambda nb, w, h: Detector(0, nb, w, h, lib=lib), seed, side=64, n_images=2)
+
+
+def test_capacity_by_lines_first_and_last_in_full_batch(lib):
+    """Emulated twin of the GPU test of the same name (packed full records sized from the board record's circle
+    count and written from the result record's)."""
+    det = Detector(0, 4, 3000, 300, lib=lib)
+    parity.check_capacity_by_lines_in_full_batch(det, [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in (0, 1)])
+    det.close()

@@ -216,6 +216,17 @@ def test_capacity_overflow_is_reported_not_truncated():
     # a context one unit too small for a crowded image reports it: see test_capacity_grows_with_the_context_area
 
 
+def test_capacity_by_lines_first_and_last_in_full_batch():
+    """k_line_peaks' overflow left the record's circle count standing while the board record said 0; the packed
+    full record was sized from one and written from the other (overrun into the next image's record / past the buffer)."""
+    det = Detector(0, 4, 3000, 300)
+    parity.check_capacity_by_lines_in_full_batch(det, [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in (0, 1)])
+    det.close()
+    det = Detector(0, 2, 3000, 300)          # two device passes: the overflowing strip is alone-first in one, last in the other
+    parity.check_capacity_by_lines_in_full_batch(det, [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in (2, 3)])
+    det.close()
+
+
 def test_hysteresis_pass_budget_growth():
     """A weak edge that snakes through many tiles and is anchored by a single strong seed needs more hysteresis passes than the
     one plain launch a fresh context starts with: the rest runs inside the persistent tail kernel (grid barriers between passes),
