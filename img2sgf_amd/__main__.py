@@ -24,16 +24,27 @@ def main(argv=None):
     ap.add_argument("--threshold", type=int, default=0, help="Hough-lines threshold (0 = choose_threshold)")
     ap.add_argument("--black-threshold", type=int, default=128)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--opencv", metavar="VERSION", help="restate this OpenCV release's arithmetic (e.g. 4.2.0, 4.8.1); default: the "
-                    "package defaults = OpenCV 4.3 .. 4.5.1 (Params.opencv_switches)")
+    ap.add_argument("--opencv", metavar="VERSION|auto", help="restate this OpenCV release's arithmetic (e.g. 4.2.0, 4.8.1), or 'auto': "
+                    "probe the cv2 installed next to this package for what it computes (Params.from_cv2); default: the package "
+                    "defaults = OpenCV 4.3 .. 4.5.1 (Params.opencv_switches).  The active switch set is printed on stderr.")
     args = ap.parse_args(argv)
     inputs, out_single = args.inputs, None
     if len(inputs) == 2 and inputs[1].lower().endswith(".sgf") and not args.outdir:
         inputs, out_single = inputs[:1], inputs[1]
     import numpy as np
+    if args.opencv == "auto":
+        try:
+            import cv2
+        except ImportError:
+            ap.error("--opencv auto needs an importable cv2 to probe")
+        switches = pipeline.probe_cv2_switches(cv2)
+    else:
+        switches = pipeline.Params.opencv_switches(args.opencv) if args.opencv else {}
     params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
-                             contrast=args.contrast, brightness=args.brightness, schedule=True,
-                             **(pipeline.Params.opencv_switches(args.opencv) if args.opencv else {}))
+                             contrast=args.contrast, brightness=args.brightness, schedule=True, **switches)
+    print("OpenCV switch set: %s (%s)" % (params.switch_set(), "probed from cv2 " + cv2.__version__ if args.opencv == "auto" else
+                                          "release " + args.opencv if args.opencv else "package defaults; --opencv VERSION|auto to change"),
+          file=sys.stderr)
     # Huffman-coded JPEGs (sequential or progressive) are decoded on the GPU straight from the file bytes (bit-exact with
     # Pillow's decoder); anything else (PNG, CMYK JPEG, ...) is opened with Pillow as the reference does (img2sgf.py:651).  Rotate / crop / contrast /
     # brightness run on the GPU either way.

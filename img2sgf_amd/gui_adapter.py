@@ -12,6 +12,8 @@ cluster plotting 308-327, edit_board 955-1002, to_SGF 781-810).  The Pillow pre-
 crop 110-114, contrast / brightness 141-149) runs on the device too, bit-exact with Pillow; everything else (Tk widgets,
 logging, the board editor) keeps running the reference's own code.
 """
+import types
+
 import numpy as np
 
 from . import pipeline, preprocess
@@ -20,14 +22,25 @@ from . import pipeline, preprocess
 def install(m, detector=None, lib=None, opencv=None):
     """Patch reference module `m` in place.  Returns the adapter's state (state["det"] = the Detector in use).
 
-    opencv: the OpenCV release whose arithmetic the GPU path restates (Params.opencv_switches).  None = the release of the cv2
-    the reference itself imported (`m.cv.__version__`, which it logs at img2sgf.py:1246) -- the patched application then answers
-    as it did before the patch -- and the package defaults where that is not a version string."""
-    if opencv is None:
-        v = getattr(getattr(m, "cv", None), "__version__", None)
+    opencv: the OpenCV release whose arithmetic the GPU path restates (Params.opencv_switches), or a dict of the three switches.
+    None = what the cv2 the reference itself imported (`m.cv`) COMPUTES: the three switches are read off the live module by closed-form
+    probes of the reference's own calls (pipeline.probe_cv2_switches) -- the patched application then answers as it did before the
+    patch, whatever that module's version string says; a module that answers a probe in an unknown way raises I2sError.  Where `m.cv`
+    is not a module object with the three functions (a headless mock), its `__version__` string decides (opencv_switches: release
+    boundaries from memory), and the package defaults where there is no version string either."""
+    cvmod = getattr(m, "cv", None)
+    how = "given"
+    if isinstance(opencv, dict):
+        switches = dict(opencv)
+    elif opencv is not None:
+        switches = pipeline.Params.opencv_switches(opencv)
+    elif isinstance(cvmod, types.ModuleType) and all(callable(getattr(cvmod, f, None)) for f in ("cvtColor", "GaussianBlur", "HoughLines")):
+        switches, how = pipeline.probe_cv2_switches(cvmod), "probed"
+    else:
+        v = getattr(cvmod, "__version__", None)
         opencv = v if isinstance(v, str) and v[:1].isdigit() else None
-    switches = pipeline.Params.opencv_switches(opencv) if opencv else {}
-    state = {"det": detector, "lib": lib, "opencv": opencv, "switches": switches}
+        switches, how = (pipeline.Params.opencv_switches(opencv), "version string") if opencv else ({}, "package defaults")
+    state = {"det": detector, "lib": lib, "opencv": opencv, "switches": switches, "switches_from": how}
 
     def _detector(w, h):
         d = state["det"]
@@ -38,6 +51,13 @@ def install(m, detector=None, lib=None, opencv=None):
         return d
 
     def _params():
+        # cv.Canny(.., apertureSize=sobel.get(), L2gradient=(gradient.get()==2)) (img2sgf.py:164-165): the widgets behind the two are
+        # hidden (:1142-1182), so every user runs 3 / L1, the one flavour the kernels implement -- anything else is refused, not ignored
+        sobel, gradient = getattr(m, "sobel", None), getattr(m, "gradient", None)
+        if sobel is not None and int(sobel.get()) != 3:
+            raise pipeline.I2sError("Canny apertureSize = %d: the GPU path implements the 3 x 3 Sobel only (img2sgf.py:164)" % int(sobel.get()))
+        if gradient is not None and int(gradient.get()) == 2:
+            raise pipeline.I2sError("Canny L2gradient = True: the GPU path implements the L1 gradient norm only (img2sgf.py:165)")
         return pipeline.Params(
             canny_lo=int(m.edge_min.get()), canny_hi=int(m.edge_max.get()),      # img2sgf.py:163
             line_threshold=int(m.threshold.get()),                               # :259
@@ -56,6 +76,7 @@ def install(m, detector=None, lib=None, opencv=None):
         """img2sgf.py:117-204 with the OpenCV section (153-198) and find_grid() (546-576) on the GPU."""
         if not m.image_loaded:
             return
+        p = _params()                    # first: settings the GPU path does not implement are refused before anything is touched
         m.found_grid = m.valid_grid = m.board_ready = False
         m.log("\nProcessing image")
         if m.rotate_angle.get() != 0:
@@ -69,7 +90,6 @@ def install(m, detector=None, lib=None, opencv=None):
         m.log("Rotating / cropping / enhancing / converting to greyscale / Canny / detecting circles / finding grid on the GPU")
         h, w = xf[1][3] - xf[1][1], xf[1][2] - xf[1][0]
         d = _detector(w, h)
-        p = _params()
         p.contrast, p.brightness = int(m.contrast.get()), int(m.brightness.get())                      # :141-149 on the device
         det = d.detect_batch([raw], p, full=True, xforms=[xf])[0]
         m.input_image_np = d.fetch_source(0, 1 if raw.ndim == 2 else 3)                                # :150
@@ -99,8 +119,9 @@ def install(m, detector=None, lib=None, opencv=None):
 
     def identify_board():
         """img2sgf.py:497-543 on the cached detection (apply_black_thresh, :762-766)."""
+        p = _params()
         d = state["det"]
-        det = d.classify(0, 1, _params())[0]
+        det = d.classify(0, 1, p)[0]
         _publish_board(det)
         m.draw_histogram(m.stone_brightnesses)                                   # :535
 

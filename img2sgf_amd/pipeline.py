@@ -52,7 +52,10 @@ class Params:
         """The three version switches for an OpenCV release string such as cv2.__version__ ("4.2.0", "4.8.1.78", "3.4.9").
         Best knowledge of OpenCV's history, unpinned like the rest of rows a2-a8 (no cv2 in the build image):
         BGR2GRAY went from 14-bit to 15-bit coefficients with 4.0; GaussianBlur's 8-bit taps are error-diffused to sum 256 since
-        4.3.0 / 3.4.10; HoughLines counts its angles with floor(..) + 1 since 4.5.2 / 3.4.14."""
+        4.3.0 / 3.4.10; HoughLines counts its angles with floor(..) + 1 since 4.5.2 / 3.4.14.
+        THE RELEASE BOUNDARIES (4.3.0 / 3.4.10, 4.5.2 / 3.4.14) ARE FROM MEMORY AND UNVERIFIED: no changelog and no cv2 were within
+        reach of the build.  Wherever a live cv2 module is at hand, use Params.from_cv2(cv2) / probe_cv2_switches(cv2) instead: they
+        decide by what the module computes, not by what it is called."""
         v = tuple(int("".join(ch for ch in part if ch.isdigit()) or 0) for part in (version.split(".") + ["0", "0"])[:3])
         three = v[0] < 4
         return dict(grey_shift=14 if three else 15,
@@ -63,6 +66,12 @@ class Params:
     def for_opencv(cls, version: str, **kwargs):
         """Params whose version switches restate the given OpenCV release (see opencv_switches)."""
         return cls(**dict(cls.opencv_switches(version), **kwargs))
+
+    @classmethod
+    def from_cv2(cls, cv, **kwargs):
+        """Params whose version switches restate what the given, live cv2 module COMPUTES (probe_cv2_switches): the robust form of
+        for_opencv(cv2.__version__).  Raises I2sError if the module answers a probe in a way none of the known rules explains."""
+        return cls(**dict(probe_cv2_switches(cv), **kwargs))
 
     def switch_set(self) -> dict:
         return dict(grey_shift=self.grey_shift, gauss_kernel_mode=self.gauss_kernel_mode,
@@ -86,6 +95,99 @@ class Params:
         p.schedule = 1 if self.schedule else 0
         p.jpeg_entropy_device = int(self.jpeg_entropy_device)
         return p
+
+
+def _gauss_taps_8bit(k: int, mode: int):
+    """The 8.8 fixed-point taps of cv.GaussianBlur(.., (k, k), k) (getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED), as
+    csrc/i2s_api.hip gauss_taps computes them: mode 0 error-diffused to sum 256, mode 1 each tap rounded on its own."""
+    import math
+    sig = float(k)
+    scale2x = -0.125 / (sig * sig)
+    vals = [math.exp(float(x * x) * scale2x) for x in range(1 - k, 0, 2)]
+    mul = 1.0 / (sum(vals) * 2 + 1.0)
+    kern = [v * mul for v in vals]
+    if mode == 1:
+        half = [int(round(v * 256.0)) for v in kern]
+        return half + [int(round(mul * 256.0))] + half[::-1]
+    half, err = [], 0.0
+    for v in kern:
+        adj = v * 256.0 + err
+        v0 = int(round(adj))                   # Python's round and lrint both round half to even
+        err = adj - v0
+        half.append(v0)
+    return half + [256 - 2 * sum(half)] + half[::-1]
+
+
+def probe_cv2_switches(cv) -> dict:
+    """The three OpenCV-version switches read off a LIVE cv2 module by three closed-form probes on the very calls the
+    reference makes (img2sgf.py:153, 175, 236-244) -- what the module computes, not what its version string says:
+
+    * cv.cvtColor(rgb, COLOR_BGR2GRAY) on 20 fixed colours: (3735 c0 + 19235 c1 + 9798 c2 + 2^14) >> 15 (4.x) or
+      (1868 c0 + 9617 c1 + 4899 c2 + 2^13) >> 14 (3.x) -- the two differ on 16 of them (and on only 0.5 % of all colours);
+    * cv.GaussianBlur((k, k), k), k = 3, 5, 7, of (a) a 255 impulse: out[dy][dx] = (t_dy t_dx 255 + 2^15) >> 16, and (b) one row of 128
+      in a black image: every pixel of row c + d = (t_d 128 S + 2^15) >> 16 with S the tap sum -- (b) tells the two tap sets apart at
+      every k (k = 3: centre 44 | 45; k = 5: 27 | 26; k = 7, d = 2: 18 | 19), (a) confirms the two-pass 8.8 fixed-point arithmetic;
+    * cv.HoughLines of an image with ONE pixel at threshold 0 with the reference's three (min_theta, max_theta) pairs: every angle's
+      single vote is a local maximum (the pixel sits 200 px from both axes, so neighbouring angles hit different rho bins), hence the
+      number of lines returned IS numangle: (2, 1, 1) = cvRound(range / theta), (3, 2, 2) = floor(range / theta) + 1.
+
+    An answer none of the rules explains raises I2sError -- never a guess.  No import of anything under oracle/."""
+    import math
+    # the two coefficient sets agree on 99.5 % of all colours (2 x 1868 = 3735 + 1, 2 x 9617 = 19235 - 1): 16 colours on which they do
+    # not, and white / black / two greys on which they must
+    px = np.array([[0, 47, 90], [11, 90, 85], [23, 139, 215], [36, 207, 110], [51, 169, 15], [67, 231, 235], [86, 211, 160], [106, 196, 135],
+                   [127, 95, 245], [148, 204, 120], [168, 231, 250], [187, 239, 110], [204, 72, 20], [219, 41, 35], [232, 99, 60], [244, 123, 15],
+                   [255, 255, 255], [0, 0, 0], [128, 128, 128], [77, 77, 77]], np.uint8).reshape(4, 5, 3)
+    c = px.astype(np.int64)
+    g15 = ((3735 * c[..., 0] + 19235 * c[..., 1] + 9798 * c[..., 2] + (1 << 14)) >> 15).astype(np.uint8)
+    g14 = ((1868 * c[..., 0] + 9617 * c[..., 1] + 4899 * c[..., 2] + (1 << 13)) >> 14).astype(np.uint8)
+    assert (g15 != g14).sum() == 16
+    got = np.asarray(cv.cvtColor(px, cv.COLOR_BGR2GRAY))
+    if got.shape == g15.shape and np.array_equal(got, g15):
+        grey_shift = 15
+    elif got.shape == g14.shape and np.array_equal(got, g14):
+        grey_shift = 14
+    else:
+        raise I2sError("cv2 probe: cvtColor(BGR2GRAY) follows neither the 15-bit nor the 14-bit coefficients")
+
+    n, cc = 17, 8
+    imp = np.zeros((n, n), np.uint8)
+    imp[cc, cc] = 255
+    row = np.zeros((n, n), np.uint8)
+    row[cc, :] = 128
+    fits = []
+    for mode in (0, 1):
+        ok = True
+        for k in (3, 5, 7):
+            t = np.array(_gauss_taps_8bit(k, mode), np.int64)
+            r = k // 2
+            want_imp = np.zeros((n, n), np.int64)
+            want_imp[cc - r:cc + r + 1, cc - r:cc + r + 1] = (np.outer(t, t) * 255 + 32768) >> 16
+            want_row = np.zeros((n, n), np.int64)
+            want_row[cc - r:cc + r + 1, :] = ((t * 128 * int(t.sum()) + 32768) >> 16)[:, None]
+            ok &= np.array_equal(np.asarray(cv.GaussianBlur(imp, (k, k), k)), want_imp)
+            ok &= np.array_equal(np.asarray(cv.GaussianBlur(row, (k, k), k)), want_row)
+        fits.append(ok)
+    if fits[0] == fits[1]:
+        raise I2sError("cv2 probe: GaussianBlur's impulse / line responses match neither 8-bit tap set (sum-256 error-diffused, "
+                       "plainly rounded)")
+    gauss_kernel_mode = 0 if fits[0] else 1
+
+    one = np.zeros((256, 256), np.uint8)
+    one[200, 200] = 255
+    delta = math.pi / 180.0 * Params.angle_tolerance                     # angle_delta, img2sgf.py:52
+    counts = []
+    for lo, hi in ((math.pi / 2 - delta, math.pi / 2 + delta), (0.0, delta), (math.pi - delta, math.pi)):
+        lines = cv.HoughLines(one, rho=1, theta=math.pi / 180.0, threshold=0, min_theta=lo, max_theta=hi)
+        counts.append(0 if lines is None else len(lines))
+    if counts == [2, 1, 1]:
+        numangle_mode = 1
+    elif counts == [3, 2, 2]:
+        numangle_mode = 0
+    else:
+        raise I2sError("cv2 probe: HoughLines answers the reference's three angle ranges with %s angles; known: [2, 1, 1] and "
+                       "[3, 2, 2]" % counts)
+    return dict(grey_shift=grey_shift, gauss_kernel_mode=gauss_kernel_mode, houghlines_numangle_mode=numangle_mode)
 
 
 @dataclass

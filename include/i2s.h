@@ -107,7 +107,11 @@ typedef struct i2s_ctx i2s_ctx;
 /* Parameters = the reference's constants (img2sgf.py:43-57) and hard-wired call arguments.
  * i2s_default_params() fills in the reference's values. */
 typedef struct i2s_params {
-    int32_t canny_lo, canny_hi;        /* 50, 200            img2sgf.py:47-48, 162 */
+    int32_t canny_lo, canny_hi;        /* 50, 200            img2sgf.py:47-48, 162.  cv.Canny's other two arguments are NOT
+                                          parameters: apertureSize = 3 and L2gradient = false (the L1 norm) are the only flavour
+                                          implemented.  The reference passes sobel.get() / gradient.get() == 2 (:164-165), but the
+                                          widgets behind them are hidden (:1142-1182) and stay at 3 / L1; the GUI adapter refuses
+                                          any other value (img2sgf_amd/gui_adapter.py) instead of ignoring it. */
     float   hc_min_dist;               /* 10                 :180 */
     int32_t hc_param1, hc_param2;      /* 100, 30            :180 */
     int32_t hc_min_radius, hc_max_radius; /* 1, 30           :180  (max_radius <= 30 supported) */
