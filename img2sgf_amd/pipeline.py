@@ -131,7 +131,7 @@ def probe_cv2_switches(cv) -> dict:
       single vote is a local maximum (the pixel sits 200 px from both axes, so neighbouring angles hit different rho bins), hence the
       number of lines returned IS numangle: (2, 1, 1) = cvRound(range / theta), (3, 2, 2) = floor(range / theta) + 1.
 
-    An answer none of the rules explains raises I2sError -- never a guess.  No import of anything under oracle/."""
+    An answer none of the rules explains raises I2sError -- never a guess.  Self-contained: the checker package of the tests is not involved."""
     import math
     # the two coefficient sets agree on 99.5 % of all colours (2 x 1868 = 3735 + 1, 2 x 9617 = 19235 - 1): 16 colours on which they do
     # not, and white / black / two greys on which they must
