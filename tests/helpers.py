@@ -18,3 +18,12 @@ def synth_grey(w, h, seed):
 def load_glue_golden():
     with open(os.path.join(GOLDEN, "glue_golden.json")) as f:
         return json.load(f)
+
+
+def free_port():
+    """A TCP port on 127.0.0.1 that is free now (for a torch.distributed rendez-vous of a test: no fixed numbers, two suites on one
+    box -- or a socket of an earlier run still in TIME_WAIT -- must not collide)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]

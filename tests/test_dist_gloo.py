@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import emu_util
+from helpers import free_port
 from img2sgf_amd import dist as i2s_dist, synth
 from img2sgf_amd.pipeline import Detector
 
@@ -56,7 +57,7 @@ def _two_ranks(tmp_path, total, mode, port):
 def test_two_rank_allgather(tmp_path):
     total = 3          # uneven shards: 2 + 1
     emu_util.emu_library()     # build once before the ranks race for it
-    a = _two_ranks(tmp_path, total, "emu", 29611)
+    a = _two_ranks(tmp_path, total, "emu", free_port())
     det = Detector(0, 2, 300, 260, lib=emu_util.emu_library())
     imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(total)]
     single = i2s_dist.boards_to_numpy(det.detect_batch(imgs, full=False))
@@ -71,7 +72,7 @@ def test_eight_rank_allgather_uneven_shards(tmp_path, total):
     differ in size (11 -> 2,2,2,1,1,1,1,1; 5 -> three ranks own nothing), every rank sends records_per_rank records with a zeroed
     tail, compact() must drop the padding, and all eight tables must equal the single-process run."""
     emu_util.emu_library()
-    a = _ranks(tmp_path, total, "emu", 29621 + total, 8)
+    a = _ranks(tmp_path, total, "emu", free_port(), 8)
     assert a.shape == (total, 384)
     det = Detector(0, 2, 300, 260, lib=emu_util.emu_library())
     imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(total)]
@@ -163,7 +164,7 @@ def test_two_ranks_real_hip_path_on_one_gpu(tmp_path):
     devices); rank r owns the contiguous seed shard shard_range(total, r, 2); both must end with the table a
     single-process run produces."""
     total = 7          # uneven shards: 4 + 3
-    a = _two_ranks(tmp_path, total, "hip", 29613)
+    a = _two_ranks(tmp_path, total, "hip", free_port())
     det = Detector(0, 4, 300, 260)
     imgs = [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in range(total)]
     single = i2s_dist.boards_to_numpy(det.detect_batch(imgs, full=False))

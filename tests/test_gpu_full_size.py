@@ -30,37 +30,60 @@ def _check(table, occs, first_seed, expect_exceptions):
         assert (boards[s - first_seed] != occs[s - first_seed]).any()
 
 
-def test_config2_4096_diagrams_one_gpu():
+def _cuda_batch(seeds):
     import torch
-    dev, occs = synth.synth_batch_torch(range(4096), torch.device("cuda", 0))
-    sd = StreamedDetector(0, 3, 256, 1024, 1024)
+    return synth.synth_batch_torch(seeds, torch.device("cuda", 0))
+
+
+def run_config2(n, make_batch=_cuda_batch, streams=3, pass_size=256, side=1024, lib=None, size=(19, 19)):
+    """configs[2] at any size (the emulated twin in test_preflight_gpu_suite.py runs it with a handful of small diagrams)."""
+    dev, occs = make_batch(range(n))
+    sd = StreamedDetector(0, streams, pass_size, side, side, lib=lib)
     boards = sd.detect_device(dev, Params())
     again = sd.detect_device(dev, Params())
     sd.close()
     table = i2s_dist.boards_to_numpy(boards)
-    assert table.shape == (4096, 384)
+    assert table.shape == (n, 384)
     _check(table, occs, 0, [])
-    assert all(b.status == 0 and b.hsize == 19 and b.vsize == 19 for b in boards)
+    assert all(b.status == 0 and (b.hsize, b.vsize) == size for b in boards)
     np.testing.assert_array_equal(i2s_dist.boards_to_numpy(again), table)      # bit-stable run to run
 
 
-def test_config3_workload_32768_diagrams_in_eight_shards():
-    import torch
-    total, world = 32768, 8
-    g = i2s_dist.BoardGather(0, 1, 0, total, i2s_dist.BoardGather.unique_id())
-    sd = StreamedDetector(0, 3, 256, 1024, 1024)
-    occs_all = np.empty((total, 19, 19), np.uint8)
+def run_config3(total, world, exceptions, make_batch=_cuda_batch, streams=3, pass_size=256, side=1024, lib=None):
+    """configs[3]'s workload on one device: the `world` contiguous shards one after the other, records deposited on the device at
+    their place of the gather buffer, ONE all-gather on a one-rank communicator, the `world`-rank layout compacted."""
+    g = i2s_dist.BoardGather(0, 1, 0, total, i2s_dist.BoardGather.unique_id(lib), lib=lib)
+    sd = StreamedDetector(0, streams, pass_size, side, side, lib=lib)
+    occs_all = None
     for r in range(world):
         lo, hi = i2s_dist.shard_range(total, r, world)
-        assert (lo, hi) == (4096 * r, 4096 * (r + 1))
-        dev, occs = synth.synth_batch_torch(range(lo, hi), torch.device("cuda", 0))
+        if hi == lo:
+            continue
+        dev, occs = make_batch(range(lo, hi))
+        if occs_all is None:
+            occs_all = np.empty((total,) + occs.shape[1:], np.uint8)
         occs_all[lo:hi] = occs
         sd.detect_device(dev, Params(), sink=g.sink(lo))          # records stay on the device, at the shard's place
         del dev
     table = g.allgather(sd.dets[0])
     assert table.shape == (total, 384)
-    _check(table, occs_all, 0, [15634])       # rank 3's shard holds the one exception below 32768
-    # the eight-rank layout of the same table: cap = 4096 records per rank, no padding; compact() returns image order
-    assert i2s_dist.records_per_rank(total, world) == 4096
-    np.testing.assert_array_equal(i2s_dist.compact(table.copy(), total, world), table)
+    _check(table, occs_all, 0, exceptions)
+    # the `world`-rank layout of the same table: cap records per rank, padded where the shards are uneven; compact() returns image order
+    cap = i2s_dist.records_per_rank(total, world)
+    padded = np.zeros((world * cap, 384), np.uint8)
+    for r in range(world):
+        lo, hi = i2s_dist.shard_range(total, r, world)
+        padded[r * cap:r * cap + hi - lo] = table[lo:hi]
+    np.testing.assert_array_equal(i2s_dist.compact(padded, total, world), table)
     sd.close(); g.close()
+
+
+def test_config2_4096_diagrams_one_gpu():
+    run_config2(4096)
+
+
+def test_config3_workload_32768_diagrams_in_eight_shards():
+    total, world = 32768, 8
+    assert [i2s_dist.shard_range(total, r, world) for r in range(world)] == [(4096 * r, 4096 * (r + 1)) for r in range(world)]
+    assert i2s_dist.records_per_rank(total, world) == 4096
+    run_config3(total, world, [15634])        # rank 3's shard holds the one exception below 32768

@@ -16,23 +16,29 @@ pytestmark = pytest.mark.gpu
 N_SEEDS = int(os.environ.get("I2S_FUZZ_JPEG_SEQ_SEEDS", 6))
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_fuzz_jpeg_call_sequences_on_one_context(seed):
-    rng = np.random.default_rng(210000 + seed)
-    nb = int(rng.integers(1, 5))
-    det = Detector(0, nb, 310, 310)
-    ref = Detector(0, nb, 310, 310)
-    for call in range(8):
-        pairs = [_encode_random(rng) for _ in range(int(rng.integers(1, 10)))]
+def run_jpeg_call_sequence(det, ref, rng, tag, n_calls=8, max_files=9):
+    """The sequence itself (also driven by the emulated twin in test_preflight_gpu_suite.py, shorter)."""
+    nb = det.max_batch
+    for call in range(n_calls):
+        pairs = [_encode_random(rng) for _ in range(int(rng.integers(1, max_files + 1)))]
         blobs, pix = [p[0] for p in pairs], [p[1] for p in pairs]
         sched = bool(rng.random() < 0.3)
         p = Params(jpeg_entropy_device=int(rng.integers(0, 3)), schedule=sched)
         got = det.detect_jpeg(blobs, p, full=False)
         want = ref.detect_batch(pix, Params(schedule=sched), full=False)
         for k in range(len(blobs)):
-            assert bytes(got[k]) == bytes(want[k]), (seed, call, k)
+            assert bytes(got[k]) == bytes(want[k]), (tag, call, k)
         if not sched:
             n_last = (len(blobs) - 1) % nb + 1
             for q in range(n_last):
-                np.testing.assert_array_equal(det.fetch_source(q, 3), pix[len(blobs) - n_last + q], err_msg="seed %d call %d image %d" % (seed, call, q))
+                np.testing.assert_array_equal(det.fetch_source(q, 3), pix[len(blobs) - n_last + q], err_msg="seed %s call %d image %d" % (tag, call, q))
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_jpeg_call_sequences_on_one_context(seed):
+    rng = np.random.default_rng(210000 + seed)
+    nb = int(rng.integers(1, 5))
+    det = Detector(0, nb, 310, 310)
+    ref = Detector(0, nb, 310, 310)
+    run_jpeg_call_sequence(det, ref, rng, seed)
     det.close(); ref.close()

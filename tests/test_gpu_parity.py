@@ -8,7 +8,7 @@ import pytest
 
 import parity
 import switches
-from helpers import GOLDEN, load_glue_golden, synth_grey
+from helpers import GOLDEN, free_port, load_glue_golden, synth_grey
 from img2sgf_amd import synth
 from img2sgf_amd.pipeline import Detector, Params, board_to_sgf
 from oracle import cv_oracle as cvo
@@ -185,7 +185,7 @@ def test_bench_under_torchrun_single_rank():
     import sys
     root = os.path.dirname(os.path.dirname(GOLDEN))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
            "--batch", "96", "--pass-size", "32", "--streams", "2", "--roofline-images", "32", "--no-cpu"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
