@@ -1,7 +1,7 @@
 """Latency of ONE call -- the reference's interactive use (its Tk loop calls process_image once per slider move, img2sgf.py:1077-1191;
 BASELINE configs[1]): host numpy image in, board record / full Detection out, for a 1024 x 1024 synthetic diagram and for the reference's
 ex1.jpg after its default contrast step; batch sizes 1, 4, 16 for comparison.  Also the sum of the call's kernel durations
-(i2s_last_kernel_timing) -- what is left is launches, memsets, copies and the final synchronisation.  For DESIGN.md 6c."""
+(i2s_last_kernel_timing) -- what is left is launches, memsets, copies and the final synchronisation.  For profiles/HISTORY.md 6c."""
 import os
 import statistics
 import sys
