@@ -167,9 +167,22 @@ def algorithm_exceptions():
     return _EXCEPTIONS
 
 
-def expected_boards(seeds, occs):
+def exceptions_switch_set():
+    """The OpenCV switch set (Params.switch_set() keys) the exception list was generated under."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_exceptions.json")) as f:
+        return json.load(f)["opencv_switches"]
+
+
+def expected_boards(seeds, occs, switches=None):
     """The boards a correct run of the hot path returns for `seeds`: the generator's occupancies `occs` (B, 19, 19), with the
-    algorithm's own answer substituted for the few seeds of algorithm_exceptions().  Returns (boards, exception seeds in range)."""
+    algorithm's own answer substituted for the few seeds of algorithm_exceptions().  Returns (boards, exception seeds in range).
+    switches: the run's Params.switch_set(); the list was searched and confirmed under ONE switch set and is refused for any other
+    (another angle count or tap set may read other seeds differently)."""
+    if switches is not None and dict(switches) != exceptions_switch_set():
+        raise ValueError("synth_exceptions.json was generated under %s, the run uses %s: regenerate it "
+                         "(tools/synth_mismatches.py, tests/golden/make_synth_exceptions.py)" % (exceptions_switch_set(), dict(switches)))
     exc = algorithm_exceptions()
     want = np.array(occs, np.uint8, copy=True)
     hit = []

@@ -3,13 +3,11 @@
 // A minimal single-threaded emulation of the slice of the HIP programming model that
 // img2sgf_amd/csrc uses, so that the *unmodified* kernel and host sources can be compiled with g++
 // (-I tests/emu puts this file in front of the real <hip/hip_runtime.h>) and exercised against the
-// oracle in the GPU-less build container.  Every GPU thread of a workgroup is a ucontext fiber;
+// oracle in the GPU-less build container.  Every GPU thread of a workgroup is a fiber (own stack, user-space switch);
 // __syncthreads() and the wave-level primitives yield to a scheduler that advances 64-lane waves in
 // lockstep.  hipMalloc'd memory is filled with 0xCD so reads of uninitialised device memory show up.
 // It catches indexing / logic errors; it does not model caches, memory ordering or performance.
 #pragma once
-#include <ucontext.h>
-
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

@@ -11,7 +11,7 @@ State* cur = &g_host_state;
 namespace {
 constexpr size_t STACK = 256 * 1024;
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;           // saved stack pointer while the fiber is not running
     char* stack = nullptr;
     State st;
     YieldKind kind = Y_NONE;
@@ -19,16 +19,55 @@ struct Fiber {
     unsigned long long seq = 0;   // wave-op sequence number
 };
 std::vector<Fiber*> g_pool;
-ucontext_t g_sched;
+void* g_sched_sp = nullptr;      // the scheduler's saved stack pointer while a fiber runs
 Fiber* g_running = nullptr;
 const std::function<void()>* g_body = nullptr;
 
-void trampoline()
+// Context switch in user space: callee-saved registers and the stack pointer only.  (glibc's swapcontext also saves and restores
+// the signal mask -- two system calls per switch, and a workgroup of 1024 fibers switches thousands of times per barrier: a third
+// of the emulated suite's time went to the kernel.)  x86-64 System V only, like the container.
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+static_assert(sizeof(void*) == 8, "x86-64 only");
+
+extern "C" void hipemu_trampoline()
 {
     (*g_body)();
     g_running->done = true;
     g_running->kind = Y_DONE;
-    swapcontext(&g_running->ctx, &g_sched);
+    hipemu_switch(&g_running->sp, g_sched_sp);
+    abort();                       // a finished fiber is never resumed
+}
+
+// A fresh fiber: its first hipemu_switch pops six zeroed registers and "returns" into the trampoline with the stack aligned as at a call.
+void arm_fiber(Fiber* f)
+{
+    void** sp = reinterpret_cast<void**>(f->stack + STACK);          // 16-byte aligned (mmap)
+    *--sp = nullptr;                                                  // the trampoline's (never used) return address: rsp = 8 mod 16 at entry
+    *--sp = reinterpret_cast<void*>(&hipemu_trampoline);
+    for (int i = 0; i < 6; i++) *--sp = nullptr;
+    f->sp = sp;
 }
 
 Fiber* get_fiber(size_t i)
@@ -46,7 +85,7 @@ void resume(Fiber* f)
 {
     g_running = f;
     cur = &f->st;
-    swapcontext(&g_sched, &f->ctx);
+    hipemu_switch(&g_sched_sp, f->sp);
     cur = &g_host_state;
     g_running = nullptr;
 }
@@ -57,7 +96,7 @@ void yield(YieldKind k)
     Fiber* f = g_running;
     if (!f) return;     // called from host code: no-op
     f->kind = k;
-    swapcontext(&f->ctx, &g_sched);
+    hipemu_switch(&f->sp, g_sched_sp);
 }
 
 // Publishes v for this lane, yields until every live lane of the wave has published, then returns
@@ -99,11 +138,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body)
             f->st.bDim = block; f->st.gDim = grid;
             f->st.linear = (int)t; f->st.lane = (int)(t % 64); f->st.wave = (int)(t / 64);
             memset(f->st.stamp, 0, sizeof(f->st.stamp));
-            getcontext(&f->ctx);
-            f->ctx.uc_stack.ss_sp = f->stack;
-            f->ctx.uc_stack.ss_size = STACK;
-            f->ctx.uc_link = nullptr;
-            makecontext(&f->ctx, trampoline, 0);
+            arm_fiber(f);
         }
         std::vector<char> blocked(nwaves, 0), finished(nwaves, 0);
         size_t nfinished = 0;

@@ -38,7 +38,13 @@ def entry(seed):
 
 if __name__ == "__main__":
     seeds = [int(s) for s in sys.argv[1:]]
+    from oracle import cv_oracle as cvo
+    c = cvo.DEFAULT_COMPAT
     doc = {"what": "synthetic-workload seeds whose board by the reference's algorithm (oracle) differs from the generator's occupancy",
+           # the OpenCV switch set the oracle ran under (its defaults = the package's): the list holds for this set only -- bench.py and
+           # the full-size tests hand their Params' set to synth.expected_boards, which refuses any other
+           "opencv_switches": {"grey_shift": int(c["grey_shift"]), "gauss_kernel_mode": int(c["gauss_kernel_mode"]),
+                               "houghlines_numangle_mode": int(c["houghlines_numangle"])},
            "searched": "seeds 0 .. 65535 (GPU path, tools/synth_mismatches.py), each confirmed here by the oracle",
            "seeds": {str(s): entry(s) for s in seeds}}
     with open(OUT, "w") as f:

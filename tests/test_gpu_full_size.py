@@ -22,7 +22,7 @@ def _check(table, occs, first_seed, expect_exceptions):
     """Every board equals the generator's occupancy -- except the seeds the reference's algorithm itself reads differently
     (synth.algorithm_exceptions, oracle-generated data): there the board must be the algorithm's."""
     boards = table[:, :361].reshape(-1, 19, 19)
-    want, hit = synth.expected_boards(range(first_seed, first_seed + len(occs)), occs)
+    want, hit = synth.expected_boards(range(first_seed, first_seed + len(occs)), occs, Params().switch_set())
     assert hit == expect_exceptions
     bad = np.nonzero((boards != want).any(axis=(1, 2)))[0]
     assert len(bad) == 0, "%d boards differ from the expected ones, first seed %d" % (len(bad), first_seed + bad[0])

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from img2sgf_amd import synth
 
@@ -34,3 +35,9 @@ def test_algorithm_exceptions_are_what_the_oracle_answers():
     occs = np.stack([synth.occupancy(s) for s in (15633, 15634)])
     want, hit = synth.expected_boards([15633, 15634], occs)
     assert hit == [15634] and (want[0] == occs[0]).all() and (want[1] == exc[15634]).all()
+    # the list holds for the switch set it was generated under -- the package defaults -- and is refused for any other
+    from img2sgf_amd.pipeline import Params
+    assert synth.exceptions_switch_set() == Params().switch_set()
+    synth.expected_boards([15633, 15634], occs, Params().switch_set())
+    with pytest.raises(ValueError, match="regenerate"):
+        synth.expected_boards([15633, 15634], occs, Params.for_opencv("4.8.1").switch_set())
