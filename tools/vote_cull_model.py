@@ -42,7 +42,7 @@ def model(plane):
     octant = (sx < 0) * 4 + (sy < 0) * 2 + (np.abs(sx) > np.abs(sy)) * 1
     binx, biny = x // EB, y // EB
     out = dict(records=len(x), today_batches=0, today_lanes=0, today_items=0, oct_batches_test=0, oct_batches_all=0, oct_lanes=0,
-               oct_groups=0, oct_groups_skipped=0, oct_items=0)
+               oct_groups=0, oct_groups_skipped=0, oct_items=0, today_batches_all_both=0)
     for ty in range(0, h, VT):
         for tx in range(0, w, VT):
             lx0, ly0 = tx - 1, ty - 1
@@ -63,6 +63,8 @@ def model(plane):
             for k in np.unique(key):
                 m = key == k
                 n = int(m.sum())
+                if bool(in_p[m].all() and in_n[m].all()):
+                    out["today_batches_all_both"] = out.get("today_batches_all_both", 0) + -(-n // 64)
                 out["today_batches"] += -(-n // 64)
                 out["today_lanes"] += n
                 out["today_items"] += int(in_p[m].sum() + in_n[m].sum())
@@ -104,6 +106,8 @@ if __name__ == "__main__":
         print("  %-20s %10.0f" % (k, v / n))
     tb, tl = tot["today_batches"] / n, tot["today_lanes"] / n
     print("  today: %.0f batches, %.1f records per batch (of 64), %.2f items per loaded record" % (tb, tl / tb, tot["today_items"] / tot["today_lanes"]))
+    print("  today: %.0f batches (%.0f%%) lie in bins all of whose records reach in BOTH directions (no test needed)" % (
+        tot["today_batches_all_both"] / n, 100.0 * tot["today_batches_all_both"] / tot["today_batches"]))
     ob = (tot["oct_batches_test"] + tot["oct_batches_all"]) / n
     print("  octant sub-lists, one batch per (bin, octant, direction) group at best-case classification: %.0f batches (%.0f test + %.0f all), "
           "%.1f records per batch, %.0f%% of the groups skipped" % (ob, tot["oct_batches_test"] / n, tot["oct_batches_all"] / n,
