@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 5's FIRST call on a GPU box after GPU use reopens, everything in ONE gpurun call because a reopening may
+# be short:   gpurun --timeout 2400 -- 'bash tools/r05_gpu_session.sh'
+# 1. the suite the driver runs, exactly as it runs it; 2. the bench exactly as the driver runs it (20 / 5); 3. smoke();
+# 4. the round's profiles (tools/profile_round.sh r05).  Logs under gpurun_out/r05/ ; the csrc hash ties every log to its sources.
+set -u
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r05; mkdir -p $O
+cat img2sgf_amd/csrc/*.h img2sgf_amd/csrc/*.hip img2sgf_amd/csrc/isa/* include/* | sha256sum | cut -d' ' -f1 > $O/csrc_sha256.txt
+echo "csrc sha256: $(cat $O/csrc_sha256.txt)"
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/gputests.log 2>&1; tail -4 $O/gputests.log
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench_20_5.err; head -c 400 $O/bench_20_5.json; echo
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 900 bash tools/profile_round.sh r05 > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
