@@ -363,11 +363,12 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
         if (left <= 0) {
             // the limit: which files still have work scheduled?  They go to the serial decoder (whatever k_je_write leaves of them
             // below is replaced by its upload, their verdicts are reset); every other file's states are final
-            int* d_pend = ctx->d_jstatus;                       // (zeroed by the caller; k_je_scan / k_je_write have not run yet)
+            // (the mask has its own half of d_jstatus, zeroed by jpeg_entropy_pass, and STAYS: k_je_scan / k_je_write below skip the
+            // files in it -- until round 5 they ran on those files' unconverged entry states and the host wiped what they wrote)
+            int* d_pend = ctx->d_jstatus + ctx->max_batch;
             hipLaunchKernelGGL(k_je_pending, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_stamp, round, d_pend);
             I2S_HIP(hipGetLastError());
             I2S_HIP(hipMemcpyAsync(ctx->h_jstatus, d_pend, (size_t)ctx->max_batch * sizeof(int), hipMemcpyDeviceToHost, st));
-            I2S_HIP(hipMemsetAsync(d_pend, 0, (size_t)ctx->max_batch * sizeof(int), st));
             const double t1 = now_ms();
             I2S_HIP(hipStreamSynchronize(st));
             ctx->jpeg_ms[2] += (float)(now_ms() - t1);
@@ -388,15 +389,10 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     }
     ctx->je_rounds = (int)round;
     ctx->je_handed_back = (int)handed.size();
-    hipLaunchKernelGGL(k_je_scan, dim3(cdiv((int)segs.size(), 4)), dim3(256), 0, st, d_segs, (int)segs.size(), d_acc, d_base, ctx->d_jstatus);
-    hipLaunchKernelGGL(k_je_write, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_tabs, d_blob, d_E, d_base, ctx->d_jstatus);
+    const int* d_skip = ctx->d_jstatus + ctx->max_batch;      // files handed back at the limit: no verdict, no coefficient is written for them
+    hipLaunchKernelGGL(k_je_scan, dim3(cdiv((int)segs.size(), 4)), dim3(256), 0, st, d_segs, (int)segs.size(), d_acc, d_base, ctx->d_jstatus, d_skip);
+    hipLaunchKernelGGL(k_je_write, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_tabs, d_blob, d_E, d_base, ctx->d_jstatus, d_skip);
     I2S_HIP(hipGetLastError());
-    for (int i : handed) {
-        // an unfinished parse has no verdict, and what it wrote is wiped: the serial decoders start from zeroed coefficients
-        I2S_HIP(hipMemsetAsync(ctx->d_jstatus + i, 0, sizeof(int), st));
-        for (int c = 0; c < files[i].ncomp; c++)
-            I2S_HIP(hipMemsetAsync(const_cast<int16_t*>(ctx->h_jd[i].coef[c]), 0, (size_t)files[i].c[c].bw * files[i].c[c].bh * 64 * sizeof(int16_t), st));
-    }
     return I2S_OK;
 }
 
@@ -410,7 +406,7 @@ static int jpeg_entropy_pass(i2s_ctx* ctx, int nb, const std::vector<JpegFile>& 
     const float w_in = ctx->jpeg_ms[2];
     struct Span { i2s_ctx* c; double t; float w; ~Span() { c->jpeg_ms[1] += (float)(now_ms() - t) - (c->jpeg_ms[2] - w); } } span{ctx, t_in, w_in};
     I2S_HIP(hipMemsetAsync(ctx->d_jpg, 0, ncoef, ctx->stream));                      // coefficients start at zero
-    I2S_HIP(hipMemsetAsync(ctx->d_jstatus, 0, (size_t)nb * sizeof(int), ctx->stream));
+    I2S_HIP(hipMemsetAsync(ctx->d_jstatus, 0, (size_t)2 * ctx->max_batch * sizeof(int), ctx->stream));     // verdicts and the hand-back mask
     // mode 1: sequential files and the first passes of progressive files on the device (parallel inside every scan), the
     // refinement passes of the latter afterwards on the host threads; mode 2: progressive files one lane per file on the device
     for (int i = 0; i < nb; i++) (mode == 0 ? host : (files[i].progressive && mode == 2 ? lanes : par)).push_back(i);

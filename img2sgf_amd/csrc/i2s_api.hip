@@ -77,7 +77,7 @@ struct i2s_ctx {
     uint8_t* d_jh = nullptr;     // entropy decoding on the device: file bytes | Huffman tables | scans | images | status (grown on demand)
     size_t jh_bytes = 0;
     int* h_jstatus = nullptr;    // [max_batch] pinned
-    int* d_jstatus = nullptr;    // [max_batch] verdicts of the device decoders
+    int* d_jstatus = nullptr;    // [max_batch] verdicts of the device decoders, [max_batch] files the parallel decoder handed back (skip mask)
     uint8_t* d_je = nullptr;     // parallel entropy decoding (k_jpeg_entropy.h): bytes | tables | scans | segments | per-subsequence state (grown on demand)
     size_t je_bytes = 0;
     uint32_t* h_jflag = nullptr; // pinned
@@ -258,7 +258,7 @@ static int create_impl(i2s_ctx* ctx)
     I2S_HIP(hipHostMalloc(&ctx->h_jd, nb * sizeof(JpgDesc)));
     I2S_HIP(hipHostMalloc(&ctx->h_jstatus, nb * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_jflag, sizeof(uint32_t)));
-    I2S_HIP(hipMalloc(&ctx->d_jstatus, nb * sizeof(int)));
+    I2S_HIP(hipMalloc(&ctx->d_jstatus, 2 * nb * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_flags, (2 * HYST_MAX_PASSES + 4) * sizeof(int)));
     I2S_HIP(hipHostMalloc(&ctx->h_flags, 2 * sizeof(int)));
     I2S_HIP(hipMalloc(&ctx->d_cent_list, nb * NVAR * g.cent_cap * sizeof(unsigned)));

@@ -279,12 +279,15 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_pending(const JeScan* __restric
 
 // grid (segments of the pass / 4), block 256: one wave per segment.  base[g] = blocks completed and DC sums before subsequence
 // g (running sums of accs over the segment); a segment whose parse holds fewer blocks than its interval marks the file bad.
+// skip[file] != 0: the iteration stopped at its round limit with work of this file still scheduled (k_je_pending) -- its states are not
+// at their fixed point, the file goes to the serial decoder, and neither a verdict nor a coefficient of it is written here.
 __global__ __launch_bounds__(256) void k_je_scan(const JeSeg* __restrict__ segs, int nseg, const JeAcc* __restrict__ accs, JeAcc* __restrict__ base,
-                                                 int* __restrict__ status)
+                                                 int* __restrict__ status, const int* __restrict__ skip)
 {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (s >= nseg) return;
     const JeSeg sg = segs[s];
+    if (skip[sg.file]) return;                                   // wave-uniform: one segment per wavefront
     const uint32_t n = sg.nbytes == 0 ? 1u : (sg.nbytes + JE_SUB_BYTES - 1) / JE_SUB_BYTES;
     JeAcc carry = {0, {0, 0, 0}, -1};
     bool bad = false;
@@ -316,7 +319,8 @@ __global__ __launch_bounds__(256) void k_je_scan(const JeSeg* __restrict__ segs,
 // grid / block as k_je_sync: every subsequence once more, from its exact entry state, coefficients stored.
 __global__ __launch_bounds__(JE_BLOCK) void k_je_write(const JeScan* __restrict__ scans, const JeSeg* __restrict__ segs, const int* __restrict__ blk_scan,
                                                         const JpegHuff* __restrict__ tabs, const uint32_t* __restrict__ blob,
-                                                        const unsigned long long* __restrict__ E, const JeAcc* __restrict__ base, int* __restrict__ status)
+                                                        const unsigned long long* __restrict__ E, const JeAcc* __restrict__ base, int* __restrict__ status,
+                                                        const int* __restrict__ skip)
 {
     __shared__ JeShared sh;
     const JeScan& sc = scans[blk_scan[blockIdx.x]];
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(JE_BLOCK) void k_je_write(const JeScan* __restrict_
         blk0 = sg.blk0; nblk = sg.nblk; file = sg.file;
     }
     je_stage(sh, sc, tabs, blob, off_dw, active);
-    if (!active) return;
+    if (!active || skip[file]) return;
     const unsigned long long entry = j == 0 ? je_pack(0, sc.kind == 2 ? sc.ss : 0, 0) : E[g];
     JeAcc acc = base[g];
     if ((uint32_t)acc.cnt >= nblk) return;

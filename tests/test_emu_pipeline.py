@@ -410,3 +410,22 @@ def test_capacity_by_lines_first_and_last_in_full_batch(lib):
     det = Detector(0, 4, 3000, 300, lib=lib)
     parity.check_capacity_by_lines_in_full_batch(det, [synth.synth_diagram(s, geom=synth.GEOM_SMALL)[0] for s in (0, 1)])
     det.close()
+
+
+@pytest.mark.parametrize("seed", [0, 2, 5])
+def test_fuzz_seed_emulated(lib, seed):
+    """Emulated twin of tests/test_gpu_fuzz.py::test_fuzz_against_oracle: the same seeds' images and parameters (one default set, one
+    non-default switch set, one random parameter set) on the emulated kernels.  tests/stress/emulated_fuzz.py runs hundreds."""
+    from test_gpu_fuzz import run_fuzz_seed
+    run_fuzz_seed(lambda nb, w, h: Detector(0, nb, w, h, lib=lib), seed)
+
+
+def test_preprocessing_fuzz_seed_emulated(lib):
+    from test_gpu_fuzz import run_preprocessing_fuzz_seed
+    run_preprocessing_fuzz_seed(lambda nb, w, h: Detector(0, nb, w, h, lib=lib), 1)
+
+
+def test_jpeg_handback_beside_redo_emulated(lib):
+    """Emulated twin of tests/test_gpu_jpeg.py::test_handback_beside_redo_in_one_pass (the skip mask of k_je_scan / k_je_write)."""
+    from test_gpu_jpeg import run_handback_beside_redo
+    run_handback_beside_redo(lambda nb, w, h: Detector(0, nb, w, h, lib=lib))

@@ -86,12 +86,16 @@ def _random_params(rng, seed=0):
 N_SEEDS = int(os.environ.get("I2S_FUZZ_SEEDS", 60))       # raise for a longer hunt
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_fuzz_against_oracle(seed):
+def _gpu_detector(nb, w, h):
+    return Detector(0, nb, w, h)
+
+
+def run_fuzz_seed(make_detector, seed):
+    """One seed (also driven on the emulated kernels: tests/test_emu_pipeline.py, tests/stress/emulated_fuzz.py)."""
     rng = np.random.default_rng(1000 + seed)
     imgs = [_random_image(rng) for _ in range(4)]
     params, okw = _random_params(rng, seed)
-    det = Detector(0, 4, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    det = make_detector(4, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
     dets = det.detect_batch(imgs, params, full=True)
     over = [k for k, d in enumerate(dets) if d.status == 100]
     if over:
@@ -111,8 +115,12 @@ def test_fuzz_against_oracle(seed):
     det.close()
 
 
-@pytest.mark.parametrize("seed", range(max(N_SEEDS // 3, 1)))
-def test_fuzz_device_preprocessing_against_pillow(seed):
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_against_oracle(seed):
+    run_fuzz_seed(_gpu_detector, seed)
+
+
+def run_preprocessing_fuzz_seed(make_detector, seed):
     """Random rotate / crop / contrast / brightness on the device against Pillow itself (staged source bit for bit), then the
     detection against the oracle run on Pillow's result."""
     from PIL import Image
@@ -132,10 +140,15 @@ def test_fuzz_device_preprocessing_against_pillow(seed):
         imgs.append(img)
         xfs.append(preprocess.xform((w, h), angle, sel))
         wants.append(preprocess.enhance(Image.fromarray(img), contrast, brightness, rotate_angle=angle, selection=sel))
-    det = Detector(0, 3, max(x[1][2] - x[1][0] for x in xfs), max(x[1][3] - x[1][1] for x in xfs))
+    det = make_detector(3, max(x[1][2] - x[1][0] for x in xfs), max(x[1][3] - x[1][1] for x in xfs))
     dets = det.detect_batch(imgs, Params(contrast=contrast, brightness=brightness), xforms=xfs)
     for k, (img, want, d) in enumerate(zip(imgs, wants, dets)):
         np.testing.assert_array_equal(det.fetch_source(k, 1 if img.ndim == 2 else 3), want, err_msg="image %d" % k)
         if d.status != 100:
             parity.compare_detection(d, opipe.process_image(want))
     det.close()
+
+
+@pytest.mark.parametrize("seed", range(max(N_SEEDS // 3, 1)))
+def test_fuzz_device_preprocessing_against_pillow(seed):
+    run_preprocessing_fuzz_seed(_gpu_detector, seed)

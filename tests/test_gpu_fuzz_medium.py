@@ -33,14 +33,19 @@ def _medium_image(rng):
     return np.ascontiguousarray(im)
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_fuzz_medium_sizes(seed):
+def run_medium_seed(make_detector, seed, n_images=2):
+    """One seed (also driven on the emulated kernels by tests/stress/emulated_fuzz.py)."""
     rng = np.random.default_rng(130000 + seed)
-    imgs = [_medium_image(rng) for _ in range(2)]
+    imgs = [_medium_image(rng) for _ in range(n_images)]
     params, okw = _random_params(rng, seed)
-    det = Detector(0, 2, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
+    det = make_detector(n_images, max(i.shape[1] for i in imgs), max(i.shape[0] for i in imgs))
     boards = det.detect_batch(imgs, params, full=False)
     imgs = [im for k, im in enumerate(imgs) if boards[k].status != 100]
     if imgs:
         parity.run_and_compare(det, imgs, params=params, internals=set(okw) <= {"compat"}, oracle_kwargs=okw)
     det.close()
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_medium_sizes(seed):
+    run_medium_seed(lambda nb, w, h: Detector(0, nb, w, h), seed)

@@ -403,3 +403,33 @@ def test_overlapping_first_passes_decode_in_file_order_on_every_path():
         for k in range(len(many)):
             np.testing.assert_array_equal(det2.fetch_source(k, 3), refs[k % len(blobs)], err_msg="copy %d" % k)
     det.close(); det2.close()
+
+
+def run_handback_beside_redo(make_detector):
+    """ONE pass in which sequential files are handed back at the round limit (k_je_pending -> the skip mask of k_je_scan /
+    k_je_write, round 5; before, those kernels ran on the files' unconverged states and the host wiped what they wrote) while
+    progressive files of the same pass take the JPG_REDO route (a run that carries past its band) and others finish on the device:
+    Pillow's pixels for every file at every limit, and the counters say the hand-back happened.  Also driven on the emulated kernels."""
+    blobs = _nonconforming_progressive_files()
+    src = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", "ex8.jpg"))
+    for kw in (dict(quality=80, subsampling=2, restart_marker_rows=1), dict(quality=60, subsampling=0), dict(quality=90, subsampling=1, restart_marker_blocks=7)):
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(src[50:250, 80:330])).save(buf, "JPEG", **kw)
+        blobs.append(buf.getvalue())
+    blobs = [blobs[k] for k in (5, 3, 0, 6, 4, 1, 7, 2)]                       # interleaved: hand-back candidates between REDO candidates
+    refs = [np.array(Image.open(io.BytesIO(b)).convert("RGB")) for b in blobs]
+    det = make_detector(len(blobs), 256, 208)
+    handed = {}
+    for limit in (1, 2, 3, 48, 1):
+        det.jpeg_set_max_rounds(limit)
+        det.detect_jpeg(blobs, Params(jpeg_entropy_device=1), full=False)
+        for k, r in enumerate(refs):
+            np.testing.assert_array_equal(det.fetch_source(k, 3), r, err_msg="file %d, round limit %d" % (k, limit))
+        handed[limit] = det.jpeg_last_handed_back()
+        assert det.jpeg_last_rounds() <= limit
+    assert handed[1] >= 2 and handed[48] == 0 and handed[1] >= handed[2] >= handed[3], handed
+    det.close()
+
+
+def test_handback_beside_redo_in_one_pass():
+    run_handback_beside_redo(lambda nb, w, h: Detector(0, nb, w, h))
