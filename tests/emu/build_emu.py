@@ -13,7 +13,17 @@ CSRC = os.path.join(ROOT, "img2sgf_amd", "csrc")
 LIB = os.path.join(HERE, "libi2s_emu.so")
 
 
-def build(force=False):
+def build(force=False, csrc=None, out=None):
+    """csrc / out: an alternative source directory and library path -- the experiments of tools/experiments/ are checked for
+    bit-exactness on the emulated kernels before they are ever timed (tools/experiments/apply.py)."""
+    global CSRC, LIB
+    if csrc is not None:
+        saved = CSRC, LIB
+        CSRC, LIB = csrc, out
+        try:
+            return build(force)
+        finally:
+            CSRC, LIB = saved
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not os.path.isdir(os.path.join(CSRC, f))] + [
         os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "gfx950_ops.h"),
         os.path.join(ROOT, "include", "i2s.h")]

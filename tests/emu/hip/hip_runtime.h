@@ -106,6 +106,17 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // wave-level barrier: on hardware only a scheduling barrier (a wave runs in lockstep); here all live lanes rendezvous
 static inline void __builtin_amdgcn_wave_barrier() { unsigned long long a[64], m; hipemu::wave_exchange(0, a, &m); }
 static inline int __lane_id() { return hipemu::cur->lane; }
+// v_mbcnt_lo / _hi: bits of the mask below this lane (per 32-bit half), plus the running count
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned add)
+{
+    const int l = hipemu::cur->lane;
+    return add + (unsigned)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u)));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add)
+{
+    const int l = hipemu::cur->lane;
+    return add + (l > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0u);
+}
 
 static inline unsigned long long __brevll(unsigned long long v)
 {

@@ -2,7 +2,7 @@
 against the fiber-based HIP emulation, csrc/isa/gfx950_ops.h replaced by plain C), many seeds, several processes -- for rounds without a
 GPU: it checks the kernels' LOGIC at HEAD against the oracle, not the machine-level paths.
 
-    python tests/stress/emulated_fuzz.py [--family fuzz|extreme|sequences|medium|preprocess|jpeg] [--first 0] [--seeds 200] [--procs 8]
+    python tests/stress/emulated_fuzz.py [--family fuzz|extreme|sequences|medium|preprocess|jpeg|fixtures] [--first 0] [--seeds 200] [--procs 8]
 """
 import argparse
 import os
@@ -50,6 +50,18 @@ def one(args):
             det, ref = mk(nb, 310, 310), mk(nb, 310, 310)
             run_jpeg_call_sequence(det, ref, rng, seed)
             det.close(); ref.close()
+        elif family == "fixtures":
+            # the reference's 18 scans x the six OpenCV switch sets (108 "seeds"): every plane, accumulator, list and record
+            import parity
+            import switches
+            from helpers import GOLDEN
+            from oracle import pipeline as opipe
+            names = ["ex%d.jpg" % i for i in range(1, 18)] + ["no_circles.jpg"]
+            name, sw = names[seed % 18], switches.NAMES[(seed // 18) % len(switches.NAMES)]
+            img = opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", name))
+            det = mk(1, img.shape[1], img.shape[0])
+            parity.run_and_compare(det, [img], params=switches.params(sw), internals=seed < 36, oracle_kwargs=dict(compat=switches.compat(sw)))
+            det.close()
         else:
             raise ValueError(family)
         return seed, None
