@@ -175,8 +175,14 @@ _DEFAULT = None
 
 
 def load():
-    """The product library (libi2s_hip.so next to this file).  Raises I2sError if it is missing."""
+    """The product library (libi2s_hip.so next to this file).  Raises I2sError if it is missing.
+    I2S_LIBRARY in the environment names another BUILD of the same library (a file called libi2s_hip.so with the same ABI version, e.g.
+    an experiment of tools/experiments/ under build/exp/): the GPU suite and the tools then run on that build.  It is never a fallback:
+    the named file must exist, load and export every symbol of include/i2s.h like the product does."""
     global _DEFAULT
     if _DEFAULT is None:
-        _DEFAULT = I2sLibrary(LIB_PATH)
+        path = os.environ.get("I2S_LIBRARY") or LIB_PATH
+        if os.path.basename(path) != os.path.basename(LIB_PATH):
+            raise I2sError("I2S_LIBRARY must name a build of %s, got %s" % (os.path.basename(LIB_PATH), path))
+        _DEFAULT = I2sLibrary(path)
     return _DEFAULT
