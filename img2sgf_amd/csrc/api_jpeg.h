@@ -361,10 +361,10 @@ static int jpeg_parallel(i2s_ctx* ctx, std::vector<int>& list, std::vector<int>&
     for (;;) {
         const int left = ctx->je_max_rounds - (int)round;
         if (left <= 0) {
-            // the limit: which files still have work scheduled?  They go to the serial decoder (whatever k_je_write leaves of them
-            // below is replaced by its upload, their verdicts are reset); every other file's states are final
-            // (the mask has its own half of d_jstatus, zeroed by jpeg_entropy_pass, and STAYS: k_je_scan / k_je_write below skip the
-            // files in it -- until round 5 they ran on those files' unconverged entry states and the host wiped what they wrote)
+            // the limit: which files still have work scheduled?  They go to the serial decoder; every other file's states are final.
+            // The mask has its own half of d_jstatus, zeroed by jpeg_entropy_pass, and STAYS: k_je_scan / k_je_write below skip the
+            // files in it, so their verdicts stay 0 and their coefficients stay zeroed for the serial decoder (until round 5 the two
+            // kernels ran on those files' unconverged entry states and the host reset / wiped what they had written)
             int* d_pend = ctx->d_jstatus + ctx->max_batch;
             hipLaunchKernelGGL(k_je_pending, dim3(nblk), dim3(JE_BLOCK), 0, st, d_scans, d_segs, d_bs, d_stamp, round, d_pend);
             I2S_HIP(hipGetLastError());
