@@ -25,21 +25,33 @@ def install(m, detector=None, lib=None, opencv=None):
     opencv: the OpenCV release whose arithmetic the GPU path restates (Params.opencv_switches), or a dict of the three switches.
     None = what the cv2 the reference itself imported (`m.cv`) COMPUTES: the three switches are read off the live module by closed-form
     probes of the reference's own calls (pipeline.probe_cv2_switches) -- the patched application then answers as it did before the
-    patch, whatever that module's version string says; a module that answers a probe in an unknown way raises I2sError.  Where `m.cv`
-    is not a module object with the three functions (a headless mock), its `__version__` string decides (opencv_switches: release
-    boundaries from memory), and the package defaults where there is no version string either."""
+    patch, whatever that module's version string says.  Where `m.cv` is not a module object with the three functions (a headless mock),
+    or where the probe fails (an answer no known rule explains: Params.from_cv2 would raise), its `__version__` string decides
+    (opencv_switches: release boundaries from memory) -- the failure is logged through `m.log` and kept in state["switches_from"] --
+    and the package defaults where there is no version string either."""
     cvmod = getattr(m, "cv", None)
     how = "given"
     if isinstance(opencv, dict):
         switches = dict(opencv)
     elif opencv is not None:
         switches = pipeline.Params.opencv_switches(opencv)
-    elif isinstance(cvmod, types.ModuleType) and all(callable(getattr(cvmod, f, None)) for f in ("cvtColor", "GaussianBlur", "HoughLines")):
-        switches, how = pipeline.probe_cv2_switches(cvmod), "probed"
     else:
-        v = getattr(cvmod, "__version__", None)
-        opencv = v if isinstance(v, str) and v[:1].isdigit() else None
-        switches, how = (pipeline.Params.opencv_switches(opencv), "version string") if opencv else ({}, "package defaults")
+        probe_error = None
+        switches = None
+        if isinstance(cvmod, types.ModuleType) and all(callable(getattr(cvmod, f, None)) for f in ("cvtColor", "GaussianBlur", "HoughLines")):
+            try:
+                switches, how = pipeline.probe_cv2_switches(cvmod), "probed"
+            except Exception as e:       # an answer no known rule explains (I2sError) or a call the module refuses: say so, do not guess silently
+                probe_error = "%s: %s" % (type(e).__name__, e)
+        if switches is None:
+            v = getattr(cvmod, "__version__", None)
+            opencv = v if isinstance(v, str) and v[:1].isdigit() else None
+            switches, how = (pipeline.Params.opencv_switches(opencv), "version string") if opencv else ({}, "package defaults")
+            if probe_error:
+                how += " (the probe of the live module failed: %s)" % probe_error
+                warn = getattr(m, "log", None)
+                if callable(warn):
+                    warn("img2sgf_amd: could not read the OpenCV arithmetic off the installed cv2 (%s); using the %s" % (probe_error, how.split(" (")[0]))
     state = {"det": detector, "lib": lib, "opencv": opencv, "switches": switches, "switches_from": how}
 
     def _detector(w, h):

@@ -127,9 +127,10 @@ def probe_cv2_switches(cv) -> dict:
     * cv.GaussianBlur((k, k), k), k = 3, 5, 7, of (a) a 255 impulse: out[dy][dx] = (t_dy t_dx 255 + 2^15) >> 16, and (b) one row of 128
       in a black image: every pixel of row c + d = (t_d 128 S + 2^15) >> 16 with S the tap sum -- (b) tells the two tap sets apart at
       every k (k = 3: centre 44 | 45; k = 5: 27 | 26; k = 7, d = 2: 18 | 19), (a) confirms the two-pass 8.8 fixed-point arithmetic;
-    * cv.HoughLines of an image with ONE pixel at threshold 0 with the reference's three (min_theta, max_theta) pairs: every angle's
-      single vote is a local maximum (the pixel sits 200 px from both axes, so neighbouring angles hit different rho bins), hence the
-      number of lines returned IS numangle: (2, 1, 1) = cvRound(range / theta), (3, 2, 2) = floor(range / theta) + 1.
+    * cv.HoughLines of an image with TWO adjacent pixels at threshold 1 with the reference's three (min_theta, max_theta) pairs: at every
+      probed angle the pair shares one rho bin and that bin is a local maximum (the pixels sit 200 px from both axes, so neighbouring
+      angles hit different rho bins), hence the number of lines returned IS numangle: (2, 1, 1) = cvRound(range / theta), (3, 2, 2) =
+      floor(range / theta) + 1.
 
     An answer none of the rules explains raises I2sError -- never a guess.  Self-contained: the checker package of the tests is not involved."""
     import math
@@ -173,12 +174,17 @@ def probe_cv2_switches(cv) -> dict:
                        "plainly rounded)")
     gauss_kernel_mode = 0 if fits[0] else 1
 
-    one = np.zeros((256, 256), np.uint8)
-    one[200, 200] = 255
+    # two adjacent pixels at (200, 200): side by side for the near-horizontal call, one above the other for the two near-vertical ones --
+    # at every probed angle the pair falls into ONE rho bin (2 votes, above threshold 1; a threshold of 0 might be refused) and
+    # neighbouring angles hit different bins (rho moves by 3.5 per degree 200 px from the axes), so each angle yields exactly one line
     delta = math.pi / 180.0 * Params.angle_tolerance                     # angle_delta, img2sgf.py:52
     counts = []
-    for lo, hi in ((math.pi / 2 - delta, math.pi / 2 + delta), (0.0, delta), (math.pi - delta, math.pi)):
-        lines = cv.HoughLines(one, rho=1, theta=math.pi / 180.0, threshold=0, min_theta=lo, max_theta=hi)
+    for (lo, hi), second in (((math.pi / 2 - delta, math.pi / 2 + delta), (200, 201)), ((0.0, delta), (201, 200)),
+                             ((math.pi - delta, math.pi), (201, 200))):
+        pair = np.zeros((256, 256), np.uint8)
+        pair[200, 200] = 255
+        pair[second] = 255
+        lines = cv.HoughLines(pair, rho=1, theta=math.pi / 180.0, threshold=1, min_theta=lo, max_theta=hi)
         counts.append(0 if lines is None else len(lines))
     if counts == [2, 1, 1]:
         numangle_mode = 1

@@ -96,10 +96,24 @@ def test_gui_adapter_fallbacks():
     assert st["switches"] == Params.opencv_switches("4.2.0") and st["switches_from"] == "given"
     st = gui_adapter.install(_fake_reference_module(MagicMock()), opencv=switches.params_kwargs("grey14"))
     assert st["switches"] == switches.params_kwargs("grey14")
+    # a live module that answers strangely: Params.from_cv2 raises; the adapter falls back to the version string and SAYS so
     bad = _oracle_backed_module()
     bad.HoughLines = lambda *a, **k: None
-    with pytest.raises(I2sError):                        # a live module that answers strangely: refuse, do not fall back silently
-        gui_adapter.install(_fake_reference_module(bad))
+    bad.__version__ = "4.5.1"
+    with pytest.raises(I2sError):
+        Params.from_cv2(bad)
+    m = _fake_reference_module(bad)
+    said = []
+    m.log = said.append
+    st = gui_adapter.install(m)
+    assert st["switches"] == Params.opencv_switches("4.5.1") and st["switches_from"].startswith("version string (the probe of the live module failed")
+    assert len(said) == 1 and "HoughLines" in said[0]
+    # ... also when a call of the module raises instead of answering
+    def boom(*a, **k):
+        raise RuntimeError("threshold must be positive")
+    bad.HoughLines = boom
+    st = gui_adapter.install(_fake_reference_module(bad))
+    assert "RuntimeError" in st["switches_from"] and st["switches"] == Params.opencv_switches("4.5.1")
 
 
 @pytest.mark.parametrize("sobel,gradient,what", [(5, 1, "apertureSize"), (7, 1, "apertureSize"), (3, 2, "L2gradient")])
