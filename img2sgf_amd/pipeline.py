@@ -682,9 +682,33 @@ def choose_threshold(img):
     return _lib.load().dll.i2s_choose_threshold(int(w), int(h))
 
 
+_HINTED = False
+
+
+def _hint_if_installed_cv2_differs(params):
+    """the package defaults restate OpenCV 4.3 .. 4.5.1; a caller who has ALREADY imported a cv2 that computes something
+    else (>= 4.5.2 counts one more angle per HoughLines call) and runs on the defaults is told once, and how to follow the module.
+    cv2 is never imported here, and nothing is changed: a hint, not a decision."""
+    global _HINTED
+    import sys
+    cv = sys.modules.get("cv2")
+    if _HINTED or params is not None or cv is None:
+        return
+    _HINTED = True
+    try:
+        theirs = probe_cv2_switches(cv)
+    except Exception:
+        return
+    if theirs != Params().switch_set():
+        import warnings
+        warnings.warn("img2sgf_amd runs on its default OpenCV switch set %s (OpenCV 4.3 .. 4.5.1), the cv2 imported in this process computes %s: "
+                      "pass Params.from_cv2(cv2) to get the boards that cv2 would give (DESIGN.md 2a)" % (Params().switch_set(), theirs), stacklevel=3)
+
+
 def process_image(input_image_np, params: Optional[Params] = None, detector: Optional[Detector] = None,
                   keep_planes=False) -> Detection:
     """img2sgf.py:117-204 from `input_image_np` (:150) on, including find_grid() (:546-576)."""
+    _hint_if_installed_cv2_differs(params)
     d = _detector_for([input_image_np], detector)
     det = d.detect_batch([input_image_np], params, full=True)[0]
     if keep_planes:

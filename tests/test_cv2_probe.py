@@ -129,3 +129,32 @@ def test_gui_adapter_refuses_canny_flavours_it_does_not_implement(sobel, gradien
         m.identify_board()
     m.image_loaded = False
     m.process_image()                                    # the reference's early return (:118) comes first
+
+
+def test_default_params_hint_when_the_imported_cv2_differs(monkeypatch):
+    """pipeline.process_image on the package defaults, in a process that has imported a cv2 whose arithmetic is another set: one
+    warning that names both sets and Params.from_cv2; none when the sets agree, when Params are given, or without a cv2."""
+    import sys
+    import warnings
+    calls = []
+    monkeypatch.setattr(pipeline, "_detector_for", lambda images, detector: (_ for _ in ()).throw(RuntimeError("stop here")))
+
+    def run(params=None):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with pytest.raises(RuntimeError, match="stop here"):
+                pipeline.process_image(np.zeros((8, 8), np.uint8), params)
+        return [str(x.message) for x in w]
+
+    monkeypatch.setattr(pipeline, "_HINTED", False)
+    monkeypatch.delitem(sys.modules, "cv2", raising=False)
+    assert run() == []
+    monkeypatch.setitem(sys.modules, "cv2", _standin(switches.params_kwargs("current")))
+    monkeypatch.setattr(pipeline, "_HINTED", False)
+    assert run(Params()) == []                                   # explicit parameters: the caller has decided
+    msgs = run()
+    assert len(msgs) == 1 and "from_cv2" in msgs[0] and "'houghlines_numangle_mode': 0" in msgs[0]
+    assert run() == []                                           # once per process
+    monkeypatch.setitem(sys.modules, "cv2", _standin(Params().switch_set()))
+    monkeypatch.setattr(pipeline, "_HINTED", False)
+    assert run() == []                                           # the installed module computes what the defaults restate
