@@ -19,6 +19,9 @@ import sys
 import types
 
 
+_MODULE_DUNDERS = {"__file__", "__name__", "__doc__", "__spec__", "__package__", "__builtins__", "__loader__"}
+
+
 def _module_bindings(tree):
     names = set()
     for node in ast.walk(tree):
@@ -45,7 +48,7 @@ def _undefined_globals(src, path, module_names):
         if table.get_type() == "function":
             for sym in table.get_symbols():
                 if sym.is_global() and sym.is_referenced() and sym.get_name() not in module_names \
-                        and not hasattr(builtins, sym.get_name()):
+                        and not hasattr(builtins, sym.get_name()) and sym.get_name() not in _MODULE_DUNDERS:
                     bad.append("%s: function %s() uses undefined name %r" % (os.path.basename(path), table.get_name(), sym.get_name()))
         for ch in table.get_children():
             walk(ch)
@@ -78,9 +81,16 @@ def check_module(path):
     bad = _undefined_globals(src, path, _module_bindings(tree))
     name = os.path.splitext(os.path.basename(path))[0]
     here = os.path.dirname(os.path.abspath(path))
-    if here not in sys.path:
-        sys.path.insert(0, here)
-    mod = importlib.import_module(name)
+    if os.path.exists(os.path.join(here, "__init__.py")) and os.path.basename(here).isidentifier():
+        # a module of a package (img2sgf_amd/pipeline.py): imported under its package name, relative imports work
+        parent = os.path.dirname(here)
+        if parent not in sys.path:
+            sys.path.insert(0, parent)
+        mod = importlib.import_module(os.path.basename(here) + "." + name)
+    else:
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        mod = importlib.import_module(name)
     base = os.path.basename(path)
 
     def resolve(node):

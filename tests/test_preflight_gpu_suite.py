@@ -28,9 +28,12 @@ from img2sgf_amd import dist as i2s_dist, synth
 HERE = os.path.dirname(os.path.abspath(__file__))
 GPU_MODULES = sorted(glob.glob(os.path.join(HERE, "test_gpu_*.py")))
 SHARED = [os.path.join(HERE, f) for f in ("parity.py", "helpers.py", "switches.py", "jpeg_transcode.py", "_dist_worker.py", "test_dist_gloo.py")]
+# the product's host layer and the bench: paths that only run on a GPU box (detect_device, BoardGather, `--opencv auto`, the roofline legs)
+PRODUCT = [os.path.join(os.path.dirname(HERE), "img2sgf_amd", f) for f in ("pipeline.py", "dist.py", "gui_adapter.py", "__main__.py", "_lib.py", "synth.py",
+                                                                            "preprocess.py")] + [os.path.join(os.path.dirname(HERE), "bench.py")]
 
 
-@pytest.mark.parametrize("path", GPU_MODULES + SHARED, ids=os.path.basename)
+@pytest.mark.parametrize("path", GPU_MODULES + SHARED + PRODUCT, ids=os.path.basename)
 def test_static_check(path):
     bad = static_check.check_module(path)
     assert not bad, "\n".join(bad)
