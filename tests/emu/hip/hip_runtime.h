@@ -1,6 +1,6 @@
 // tests/emu/hip/hip_runtime.h  --  TEST INFRASTRUCTURE ONLY (never shipped, never loaded by the product).
 //
-// A minimal single-threaded emulation of the slice of the HIP programming model that
+// A minimal emulation (one kernel at a time, host threads welcome) of the slice of the HIP programming model that
 // img2sgf_amd/csrc uses, so that the *unmodified* kernel and host sources can be compiled with g++
 // (-I tests/emu puts this file in front of the real <hip/hip_runtime.h>) and exercised against the
 // oracle in the GPU-less build container.  Every GPU thread of a workgroup is a fiber (own stack, user-space switch);

@@ -3,6 +3,8 @@
 
 #include <sys/mman.h>
 
+#include <mutex>
+
 namespace hipemu {
 
 static State g_host_state;          // used outside kernels (blockIdx etc. are meaningless there)
@@ -121,8 +123,13 @@ unsigned long long wave_exchange(unsigned long long v, unsigned long long* all, 
     return v;
 }
 
+// Kernels of several host threads (StreamedDetector: one context per thread) run ONE AT A TIME: the fibers, the scheduler and -- above
+// all -- the kernels' __shared__ arrays (function-local statics here) exist once per process.
+static std::mutex g_launch_mutex;
+
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body)
 {
+    std::lock_guard<std::mutex> one_kernel_at_a_time(g_launch_mutex);
     if (g_running) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
     const size_t nthreads = (size_t)block.x * block.y * block.z;
     const size_t nwaves = (nthreads + 63) / 64;

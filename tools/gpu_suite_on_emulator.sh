@@ -1,8 +1,7 @@
 #!/bin/bash
 # The whole `-m gpu` suite on the EMULATED kernels (no GPU): the emulated build of the product sources under the product library's name,
 # handed to the suite through I2S_LIBRARY (img2sgf_amd/_lib.py).  Every GPU test body runs as it would on a GPU box; what cannot work
-# without the hardware is listed in profiles/r05_c_emulated_runs.txt (torch.cuda tensors, RCCL, several host threads on the
-# single-threaded emulation, two round counts of the JPEG entropy iteration that depend on how workgroups are scheduled).
+# without the hardware is listed in profiles/r05_c_emulated_runs.txt (torch.cuda tensors, RCCL, two round counts of the JPEG entropy iteration that depend on how workgroups are scheduled).
 #   usage: tools/gpu_suite_on_emulator.sh [pytest args]        (~35 min on 7 processes)
 set -u
 cd "$(dirname "$0")/.."
