@@ -73,3 +73,26 @@ def test_comm_errors_have_text():
     rc = lib.dll.i2s_comm_create(C.byref(comm), 0, idb, 1, 0, 4)
     assert rc in (-2, -3)                                                           # I2S_E_NO_DEVICE / I2S_E_HIP
     assert len(lib.dll.i2s_comm_last_error(None).decode()) > 0
+
+
+def _build_c_host(tmp_path):
+    """examples/c_host.c: a C99 host (no Python, no C++) compiled with gcc -pedantic -Werror against include/i2s.h and linked with the
+    product library -- the header is valid C and the boundary carries no C++ or torch type."""
+    import subprocess
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.join(ROOT, "img2sgf_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_host.c"), "-o", exe, "-L", libdir, "-li2s_hip", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c99_host_builds_links_and_reports_no_device(tmp_path):
+    import subprocess
+    from img2sgf_amd import build
+    build.build()
+    out = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert "i2s ABI version 3; defaults: Canny 50 / 200, HoughCircles (10, 100, 30, 1, 30), black threshold 128" in out.stdout
+    # without a GPU the C host is told so (exit code 2 = I2S_E_NO_DEVICE); on a GPU box the context is created and destroyed (0)
+    assert out.returncode in (0, 2), out.stdout + out.stderr
+    if out.returncode == 2:
+        assert "no HIP device" in out.stdout

@@ -693,3 +693,21 @@ def test_blur_flags_across_passes_of_different_sizes():
         for k in range(0, len(batch), 2):
             _blur_planes_match(det, batch[k:k + 2])
     det.close()
+
+
+def test_c99_host_prints_the_reference_sgf(tmp_path):
+    """examples/c_host.c -- a plain C host on the C ABI -- on a PGM of a synthetic diagram and of a reference scan's grey plane: its
+    standard output ends with exactly the SGF text the reference's writer produces for the oracle's board (to_SGF, img2sgf.py:781-810)."""
+    import subprocess
+    from test_abi import _build_c_host
+    exe = _build_c_host(tmp_path)
+    scan = cvo.bgr2gray(opipe.load_and_enhance(os.path.join(GOLDEN, "test_images", "ex1.jpg")))
+    for name, img in (("diagram", synth.synth_diagram(5)[0]), ("ex1", scan)):
+        pgm = tmp_path / (name + ".pgm")
+        with open(pgm, "wb") as f:
+            f.write(b"P5 %d %d 255\n" % (img.shape[1], img.shape[0]) + img.tobytes())
+        out = subprocess.run([exe, str(pgm)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        ref = opipe.process_image(img)
+        assert ref["board_ready"] and out.stdout.endswith(ref["sgf"]), out.stdout[-400:]
+    assert out.stdout.endswith(EX1_SGF)                  # the grey plane of ex1 reads like ex1 itself: the reference's recorded result
