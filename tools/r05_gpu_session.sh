@@ -9,6 +9,8 @@ O=gpurun_out/r05; mkdir -p $O
 cat img2sgf_amd/csrc/*.h img2sgf_amd/csrc/*.hip img2sgf_amd/csrc/isa/* include/* | sha256sum | cut -d' ' -f1 > $O/csrc_sha256.txt
 echo "csrc sha256: $(cat $O/csrc_sha256.txt)"
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/gputests.log 2>&1; tail -4 $O/gputests.log
+# a failure under -x hides everything behind it: the whole list then, once
+grep -q " failed" $O/gputests.log && { timeout 1500 python -m pytest tests -m gpu -q -n 4 > $O/gputests_all.log 2>&1; tail -15 $O/gputests_all.log; }
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench_20_5.err; head -c 400 $O/bench_20_5.json; echo
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 timeout 900 bash tools/profile_round.sh r05 > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
