@@ -27,8 +27,8 @@ def tree(name):
     shutil.rmtree(base, ignore_errors=True)
     shutil.copytree(os.path.join(ROOT, "img2sgf_amd", "csrc"), csrc)
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(base, "include"))
-    patch = os.path.join(HERE, name + ".patch")
-    subprocess.check_call(["patch", "-p3", "-s", "-d", csrc, "-i", patch])        # paths in the patch: img2sgf_amd/csrc/<file>
+    for part in name.split("+"):                                                  # "tile128+cull_fast": several patches, in this order
+        subprocess.check_call(["patch", "-p3", "-s", "-d", csrc, "-i", os.path.join(HERE, part + ".patch")])    # paths in the patch: img2sgf_amd/csrc/<file>
     return base, csrc
 
 
