@@ -4,7 +4,7 @@
 # Output: gpurun_out/r05/ab_<NAME>.txt  (one JSON line per run: "lib", "boards_ok", us per image and kernel group).
 set -u
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/${I2S_ROUND:-r06}; mkdir -p $O
 for N in "$@"; do
   python tools/experiments/apply.py $N --hip > $O/ab_${N}_build.log 2>&1 || { echo "$N: build failed"; tail -5 $O/ab_${N}_build.log; continue; }
   : > $O/ab_$N.txt
