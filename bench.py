@@ -253,6 +253,7 @@ def main():
         d1.detect_device(noisy, params)
         seg_noisy = d1.last_kernel_timing()
         del noisy
+        arch, lib_path = d1.arch, d1.lib.path
         d1.close()
         stage_s = sum(seg.get(k, 0.0) for k in BLUR_CANNY_SEGS) * 1e-3
         stage_noisy_s = sum(seg_noisy.get(k, 0.0) for k in BLUR_CANNY_SEGS) * 1e-3
@@ -267,6 +268,7 @@ def main():
             "metric": "go-diagram images/sec (1024x1024 greyscale)", "value": images / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "device_arch": arch, "lib": os.path.relpath(lib_path, os.path.dirname(os.path.abspath(__file__))),
             "config": {"workload": "batch of %d synthetic 1024x1024 19x19 diagrams per GPU (BASELINE configs[%d]), "
                                    "device-resident, full hot path incl. board all-gather" % (B, 2 if world == 1 else 3),
                        "pass_size": pass_size, "streams": args.streams, "boards_match_generator": ok,

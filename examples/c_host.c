@@ -16,7 +16,8 @@ static unsigned char* read_pgm(const char* path, int* w, int* h)
     int maxval = 0;
     unsigned char* p = NULL;
     if (!f) return NULL;
-    if (fscanf(f, "P5 %d %d %d", w, h, &maxval) == 3 && maxval == 255 && fgetc(f) != EOF) {
+    /* sizes the library accepts (i2s_create: 1 .. 16384 per side), checked before anything is allocated from the header's numbers */
+    if (fscanf(f, "P5 %d %d %d", w, h, &maxval) == 3 && maxval == 255 && *w >= 1 && *h >= 1 && *w <= 16384 && *h <= 16384 && fgetc(f) != EOF) {
         p = (unsigned char*)malloc((size_t)*w * (size_t)*h);
         if (p && fread(p, 1, (size_t)*w * (size_t)*h, f) != (size_t)*w * (size_t)*h) { free(p); p = NULL; }
     }

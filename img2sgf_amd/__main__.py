@@ -37,12 +37,19 @@ def main(argv=None):
             import cv2
         except ImportError:
             ap.error("--opencv auto needs an importable cv2 to probe")
-        switches = pipeline.probe_cv2_switches(cv2)
+        probed = True
+        try:
+            switches = pipeline.probe_cv2_switches(cv2)
+        except Exception as e:      # a build whose Gaussian / HoughLines takes a path the probe does not know (HAL, IPP), or a cv2.error
+            probed = False
+            print("--opencv auto: the behavioural probe failed on cv2 %s (%s: %s); falling back to the release table for that version"
+                  % (cv2.__version__, type(e).__name__, e), file=sys.stderr)
+            switches = pipeline.Params.opencv_switches(cv2.__version__)
     else:
         switches = pipeline.Params.opencv_switches(args.opencv) if args.opencv else {}
     params = pipeline.Params(line_threshold=args.threshold, black_threshold=args.black_threshold,
                              contrast=args.contrast, brightness=args.brightness, schedule=True, **switches)
-    print("OpenCV switch set: %s (%s)" % (params.switch_set(), "probed from cv2 " + cv2.__version__ if args.opencv == "auto" else
+    print("OpenCV switch set: %s (%s)" % (params.switch_set(), ("probed from cv2 " if probed else "release table for cv2 ") + cv2.__version__ if args.opencv == "auto" else
                                           "release " + args.opencv if args.opencv else "package defaults; --opencv VERSION|auto to change"),
           file=sys.stderr)
     # Huffman-coded JPEGs (sequential or progressive) are decoded on the GPU straight from the file bytes (bit-exact with

@@ -84,7 +84,7 @@ class I2sXform(C.Structure):
 assert C.sizeof(I2sBoard) == 384
 assert C.sizeof(I2sResult) == 73384 + (16384 - 4096) * 13 + 4 * (1024 - 256) * 8
 
-EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
+EXPORTS = ["i2s_abi_version", "i2s_device_arch", "i2s_default_params", "i2s_choose_threshold", "i2s_strerror", "i2s_last_error",
            "i2s_create", "i2s_destroy", "i2s_detect_batch", "i2s_detect_batch_xf", "i2s_jpeg_info", "i2s_detect_jpeg_batch", "i2s_jpeg_last_rounds", "i2s_jpeg_last_handed_back", "i2s_jpeg_set_max_rounds", "i2s_jpeg_last_timing",
            "i2s_classify_batch", "i2s_grid_from_lines", "i2s_validate_grid", "i2s_find_lines",
            "i2s_fetch_plane", "i2s_fetch_source", "i2s_last_timing", "i2s_set_debug", "i2s_fetch_circle_acc", "i2s_fetch_line_acc",
@@ -92,7 +92,7 @@ EXPORTS = ["i2s_abi_version", "i2s_default_params", "i2s_choose_threshold", "i2s
            "i2s_set_board_sink", "i2s_allgather_boards",
            "i2s_set_profiling", "i2s_last_kernel_timing", "i2s_kernel_timing_name", "i2s_blur_band_stats", "i2s_hysteresis_stats"]
 NSEG = 14
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 
 
@@ -122,6 +122,7 @@ class I2sLibrary:
         L.i2s_strerror.restype = C.c_char_p
         L.i2s_last_error.argtypes = [vp]
         L.i2s_last_error.restype = C.c_char_p
+        L.i2s_device_arch.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.i2s_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
         L.i2s_destroy.argtypes = [vp]
         L.i2s_destroy.restype = None
@@ -171,6 +172,15 @@ class I2sLibrary:
             raise I2sError("ABI version mismatch in %s" % path)
 
 
+def device_arch(lib, ctx):
+    """i2s_device_arch: "gfx950:sramecc+:xnack-" on an MI355X; the CPU emulation of tests/emu answers "emulated"."""
+    buf = C.create_string_buffer(256)
+    rc = lib.dll.i2s_device_arch(ctx, buf, 256)
+    if rc != 0:
+        raise I2sError("i2s_device_arch: %s" % lib.dll.i2s_strerror(rc).decode())
+    return buf.value.decode()
+
+
 _DEFAULT = None
 
 
@@ -184,5 +194,10 @@ def load():
         path = os.environ.get("I2S_LIBRARY") or LIB_PATH
         if os.path.basename(path) != os.path.basename(LIB_PATH):
             raise I2sError("I2S_LIBRARY must name a build of %s, got %s" % (os.path.basename(LIB_PATH), path))
+        if os.path.realpath(path) != os.path.realpath(LIB_PATH):
+            # never silent: a variable left over from tools/experiments/ab.sh or tools/gpu_suite_on_emulator.sh redirects every
+            # consumer of the package (CLI, gui_adapter, bench), so each process says once which file it runs on
+            import sys
+            sys.stderr.write("img2sgf_amd: I2S_LIBRARY is set -- running on %s, NOT the product library %s\n" % (path, LIB_PATH))
         _DEFAULT = I2sLibrary(path)
     return _DEFAULT

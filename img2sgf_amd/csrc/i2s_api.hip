@@ -196,6 +196,15 @@ extern "C" const char* i2s_strerror(int code)
 
 extern "C" const char* i2s_last_error(const i2s_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
+extern "C" int i2s_device_arch(const i2s_ctx* ctx, char* buf, size_t cap)
+{
+    if (!ctx || !buf || cap == 0) return I2S_E_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return I2S_E_HIP;
+    snprintf(buf, cap, "%s", prop.gcnArchName);
+    return I2S_OK;
+}
+
 extern "C" void i2s_destroy(i2s_ctx* ctx)
 {
     if (!ctx) return;

@@ -293,6 +293,7 @@ class Detector:
             raise I2sError("i2s_create failed: %s (no CPU fallback exists)" % self.lib.dll.i2s_strerror(rc).decode())
         self.max_batch, self.max_w, self.max_h = max_batch, max_w, max_h
         self._last_shapes = []
+        self.arch = _lib.device_arch(self.lib, self._ctx)       # "gfx950..." on an MI355X ("emulated": tests/emu)
 
     def close(self):
         if self._ctx:

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define I2S_ABI_VERSION 3
+#define I2S_ABI_VERSION 4
 
 #define I2S_BOARD_SIZE 19      /* img2sgf.py:43 */
 #define I2S_NSLOTS 10          /* blur-bank slots, img2sgf.py:171-175 */
@@ -195,6 +195,10 @@ void i2s_default_params(i2s_params* p);
 int  i2s_choose_threshold(int w, int h);
 const char* i2s_strerror(int code);
 const char* i2s_last_error(const i2s_ctx* ctx);
+/* The architecture name of the device the context runs on ("gfx950:sramecc+:xnack-" on an MI355X), NUL-terminated into buf[cap];
+ * returns I2S_OK, I2S_E_INVALID for a null argument / cap == 0.  No reference counterpart: it is how a caller (and the GPU test
+ * suite) tells a context on the hardware from any other build of this ABI -- the CPU emulation used by tests/emu answers "emulated". */
+int  i2s_device_arch(const i2s_ctx* ctx, char* buf, size_t cap);
 
 /* device_id >= 0. max_batch = images processed per device pass (workspace is sized for it);
  * detect_batch accepts any B and loops over passes. */

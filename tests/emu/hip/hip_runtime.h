@@ -194,6 +194,8 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hip
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+struct hipDeviceProp_t { char gcnArchName[256]; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { snprintf(p->gcnArchName, sizeof p->gcnArchName, "emulated"); return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (!*p) return 2; memset(*p, 0xCD, n); return hipSuccess; }
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }

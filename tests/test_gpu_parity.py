@@ -21,11 +21,20 @@ IMAGES = ["ex%d.jpg" % i for i in range(1, 18)] + ["no_circles.jpg"]
 
 
 def test_native_library_loaded():
+    """The suite ran on an MI355X, on the product library: the context's device says gfx950 (the CPU emulation of tests/emu, which
+    tools/gpu_suite_on_emulator.sh puts under the product's file name, says "emulated" and fails here), and the file is
+    img2sgf_amd/libi2s_hip.so itself unless I2S_EXPERIMENT=1 declares an experiment build (tools/experiments/ab.sh)."""
     from img2sgf_amd import _lib
     lib = _lib.load()
     assert lib.path.endswith("libi2s_hip.so")
+    if os.environ.get("I2S_EXPERIMENT") != "1":
+        assert os.path.realpath(lib.path) == os.path.realpath(_lib.LIB_PATH), "I2S_LIBRARY redirects the suite to %s" % lib.path
     with open("/proc/self/maps") as f:
-        assert "libi2s_hip.so" in f.read()
+        assert os.path.realpath(lib.path) in f.read()
+    det = Detector(0, 1, 64, 64)
+    arch = det.arch
+    det.close()
+    assert arch.startswith("gfx950"), "the library's context runs on %r, not on an MI355X" % arch
 
 
 def test_small_synthetic_with_internals():

@@ -166,3 +166,21 @@ def test_jpeg_call_sequence_on_emulated_kernels():
     det, ref = Detector(0, 2, 310, 310, lib=emu), Detector(0, 2, 310, 310, lib=emu)
     js.run_jpeg_call_sequence(det, ref, rng, "emu", n_calls=2, max_files=3)
     det.close(); ref.close()
+
+
+def test_gpu_suite_on_a_cpu_library_does_not_read_as_a_gpu_run(tmp_path):
+    """with I2S_LIBRARY naming the CPU emulation under the product's file name, `pytest -m gpu -k native_library`
+    FAILS (the context's device answers "emulated", i2s_device_arch), with and without the I2S_EXPERIMENT=1 declaration, and the
+    loader says on stderr which file it runs on.  Nothing named libi2s_hip.so can make the GPU suite pass on a CPU."""
+    import shutil
+    import subprocess
+    ROOT = os.path.dirname(HERE)
+    fake = tmp_path / "libi2s_hip.so"
+    shutil.copy(emu_util.emu_library().path, fake)
+    for declared in ("0", "1"):
+        env = dict(os.environ, I2S_LIBRARY=str(fake), I2S_EXPERIMENT=declared)
+        out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k",
+                              "native_library", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert out.returncode != 0 and "1 failed" in out.stdout, out.stdout[-800:] + out.stderr[-400:]
+        assert ("I2S_LIBRARY redirects the suite" in out.stdout) if declared == "0" else ("'emulated', not on an MI355X" in out.stdout), out.stdout[-1200:]
+        assert "I2S_LIBRARY is set -- running on " + str(fake) in out.stdout + out.stderr

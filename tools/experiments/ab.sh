@@ -13,7 +13,7 @@ for N in "$@"; do
     python tools/kernel_times.py --images 256 --pass-size 256 --reps 3 --lib build/exp/$N/libi2s_hip.so | tail -1 >> $O/ab_$N.txt
   done
   # parity of the experimental build on the GPU: the parity module of the suite, through the same C ABI (I2S_LIBRARY: img2sgf_amd/_lib.py)
-  I2S_LIBRARY=$PWD/build/exp/$N/libi2s_hip.so timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "synthetic or reference_image or tiny or ragged or large or record_indices or phone or capacity" > $O/ab_${N}_parity.log 2>&1; echo "$N parity: $(tail -1 $O/ab_${N}_parity.log)"
+  I2S_EXPERIMENT=1 I2S_LIBRARY=$PWD/build/exp/$N/libi2s_hip.so timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "synthetic or reference_image or tiny or ragged or large or record_indices or phone or capacity" > $O/ab_${N}_parity.log 2>&1; echo "$N parity: $(tail -1 $O/ab_${N}_parity.log)"
   python - "$O/ab_$N.txt" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
