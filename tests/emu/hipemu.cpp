@@ -3,6 +3,8 @@
 
 #include <sys/mman.h>
 
+#include <pthread.h>
+
 #include <mutex>
 
 namespace hipemu {
@@ -23,6 +25,11 @@ struct Fiber {
 std::vector<Fiber*> g_pool;
 void* g_sched_sp = nullptr;      // the scheduler's saved stack pointer while a fiber runs
 Fiber* g_running = nullptr;
+pthread_t g_owner;               // the host thread whose run_grid() is executing fibers (valid while g_running != nullptr)
+thread_local bool t_in_launch = false;
+// `cur` and `g_running` are process globals: a host thread that is NOT the launching one (the JPEG host_job threads run beside
+// kernels of the launching thread) must never switch onto a fiber
+static inline bool on_owner_thread() { return g_running && pthread_equal(g_owner, pthread_self()); }
 const std::function<void()>* g_body = nullptr;
 
 // Context switch in user space: callee-saved registers and the stack pointer only.  (glibc's swapcontext also saves and restores
@@ -51,7 +58,9 @@ hipemu_switch:
     ret
     .size hipemu_switch, .-hipemu_switch
 )");
-static_assert(sizeof(void*) == 8, "x86-64 only");
+#if !defined(__x86_64__)
+#error "tests/emu/hipemu.cpp: the hand-written context switch is x86-64 System V only"
+#endif
 
 extern "C" void hipemu_trampoline()
 {
@@ -95,8 +104,8 @@ void resume(Fiber* f)
 
 void yield(YieldKind k)
 {
+    if (!on_owner_thread()) return;     // called from host code (this or another thread): no-op
     Fiber* f = g_running;
-    if (!f) return;     // called from host code: no-op
     f->kind = k;
     hipemu_switch(&f->sp, g_sched_sp);
 }
@@ -105,8 +114,8 @@ void yield(YieldKind k)
 // all 64 values plus the mask of lanes that took part.
 unsigned long long wave_exchange(unsigned long long v, unsigned long long* all, unsigned long long* active)
 {
+    if (!on_owner_thread()) { fprintf(stderr, "hipemu: wave op outside a kernel\n"); abort(); }
     Fiber* f = g_running;
-    if (!f) { fprintf(stderr, "hipemu: wave op outside a kernel\n"); abort(); }
     unsigned long long seq = ++f->seq;
     int par = (int)(seq & 1);
     // scratch lives in lane 0's State of this wave: find it through the pool layout
@@ -129,8 +138,10 @@ static std::mutex g_launch_mutex;
 
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body)
 {
+    if (t_in_launch) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }      // before the (non-recursive) lock: it would deadlock there
     std::lock_guard<std::mutex> one_kernel_at_a_time(g_launch_mutex);
-    if (g_running) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
+    struct InLaunch { InLaunch() { t_in_launch = true; } ~InLaunch() { t_in_launch = false; } } in_launch;
+    g_owner = pthread_self();
     const size_t nthreads = (size_t)block.x * block.y * block.z;
     const size_t nwaves = (nthreads + 63) / 64;
     g_body = &body;

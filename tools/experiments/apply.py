@@ -27,8 +27,19 @@ def tree(name):
     shutil.rmtree(base, ignore_errors=True)
     shutil.copytree(os.path.join(ROOT, "img2sgf_amd", "csrc"), csrc)
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(base, "include"))
-    for part in name.split("+"):                                                  # "tile128+cull_fast": several patches, in this order
-        subprocess.check_call(["patch", "-p3", "-s", "-d", csrc, "-i", os.path.join(HERE, part + ".patch")])    # paths in the patch: img2sgf_amd/csrc/<file>
+    parts = name.split("+")
+    for i, part in enumerate(parts):                                              # "tile128+cull_fast": several patches, in this order
+        path = os.path.join(HERE, part + ".patch")
+        if not os.path.exists(path):
+            sys.exit("no such experiment: %s (tools/experiments/%s.patch)" % (part, part))
+        with open(path) as f:                                                     # first line of a patch may say "# requires: tile128"
+            first = f.readline()
+        need = first.split(":", 1)[1].split() if first.startswith("# requires:") else []
+        missing = [n for n in need if n not in parts[:i]]
+        if missing:
+            sys.exit("%s.patch applies on top of %s only: use  apply.py %s" % (part, " + ".join(need), "+".join(need + [part])))
+        if subprocess.call(["patch", "-p3", "-s", "-d", csrc, "-i", path]) != 0:      # paths in the patch: img2sgf_amd/csrc/<file>
+            sys.exit("%s.patch does not apply to the current img2sgf_amd/csrc%s" % (part, " + " + "+".join(parts[:i]) if i else ""))
     return base, csrc
 
 
