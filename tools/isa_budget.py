@@ -62,6 +62,47 @@ def vote_step_costs(body):
     return len(idx), c
 
 
+def loops(body):
+    """(instructions, [(first, last)]) -- the natural loops of a kernel body: a branch to a label at or above itself closes one."""
+    ins, labels = [], {}
+    for l in body.splitlines():
+        l = l.strip()
+        if not l or l.startswith(";"):
+            continue
+        m = re.match(r"^(\.LBB\w+):", l)
+        if m:
+            labels[m.group(1)] = len(ins)
+        elif not l.startswith("."):
+            ins.append(l.split(";")[0].strip())
+    head = {}
+    for i, l in enumerate(ins):
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\w+)", l)
+        if m and labels.get(m.group(1), len(ins)) <= i:
+            head[labels[m.group(1)]] = max(head.get(labels[m.group(1)], 0), i)
+    return ins, sorted(head.items())
+
+
+# instruction classes that issue at half rate on gfx950 (profiles/r02_a_valu_rate_8waves.txt: 4.1 - 4.6 cycles against 2.3 - 3.0)
+HALF_RATE = re.compile(r"v_pk_|v_perm_b32|v_and_or_b32|v_lshl_or_b32|v_or3_b32|v_bfe_|v_bfi_b32|v_alignb|v_lshlrev_b32|v_mad_|v_mul_|v_cndmask|v_dot|v_min|v_max|"
+                       r"v_med3|v_add3|v_lshl_add|v_add_lshl|v_cmp|v_xad|v_sad|v_bcnt|v_cvt")
+
+
+def row_walk_costs(body):
+    """The row kernels (k_sobel_nms_rows) walk a band six rows per trip of an unrolled loop: {"bytes" | "packed": (vector instructions,
+    of which half-rate classes, scalar instructions) per 4-pixel row} for the two-valued byte walk and the 16-bit packed walk."""
+    ins, lp = loops(body)
+    out = {}
+    for a, b in lp:
+        seg = ins[a:b + 1]
+        v = [x for x in seg if x.startswith("v_")]
+        if len(v) < 300:
+            continue
+        kind = "packed" if any(x.startswith("v_pk_") for x in seg) else "bytes"
+        if kind not in out or len(v) < out[kind][0] * 6:            # the innermost of the loops that share a body
+            out[kind] = (len(v) / 6.0, sum(1 for x in v if HALF_RATE.match(x)) / 6.0, sum(1 for x in seg if x.startswith("s_")) / 6.0)
+    return out
+
+
 def vmcnt_values(body):
     return collections.Counter(int(v) for v in re.findall(r"s_waitcnt[^\n]*?vmcnt\((\d+)\)", body))
 
@@ -85,7 +126,12 @@ def report(asm):
     lines += ["", "k_vote_centres<30>: %d ds_add_u32; (vector, scalar) instructions between consecutive ones: %s" % (n, dict(c)),
               "k_blur<true>  s_waitcnt vmcnt values: %s" % dict(sorted(vmcnt_values(ks["k_blur<true>"]["body"]).items())),
               "k_blur<false> s_waitcnt vmcnt values: %s" % dict(sorted(vmcnt_values(ks["k_blur<false>"]["body"]).items())),
-              "packed f32 instructions (v_pk_*_f32) in the whole code object: %d" % packed_f32(asm)]
+              "packed f32 instructions (v_pk_*_f32) in the whole code object: %d" % packed_f32(asm), "",
+              "row walks of k_sobel_nms_rows (unrolled by 6): instructions per 4-pixel row -- vector (of which half-rate classes), scalar"]
+    for name in sorted(ks):
+        if name.startswith("k_sobel_nms_rows"):
+            for kind, (v, hr, sc) in sorted(row_walk_costs(ks[name]["body"]).items()):
+                lines.append("  %-28s %-6s walk: %6.1f vector (%5.1f half rate), %5.1f scalar  = %.1f vector per pixel" % (name, kind, v, hr, sc, v / 4))
     return "\n".join(lines)
 
 
