@@ -19,4 +19,4 @@ timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 timeout 900 bash tools/profile_round.sh r06 > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
 # 5. the experiments that were proven bit-exact on the emulated kernels while the GPU was closed (tools/experiments/): A/B timings
-timeout 3000 bash tools/experiments/ab.sh stride133 tile128 tile128+cull_fast radius_staged canny_lean tile128+vastr133 tile128+cull_fast+edge_lut+radius_pre2 edge_lut radius_pre2 cull_fast > $O/ab.log 2>&1; tail -8 $O/ab.log
+timeout 3000 bash tools/experiments/ab.sh stride133 tile128+cull_fast tile128 canny_lean edge_lut radius_staged tile128+vastr133 tile128+vastr133+cull_fast+edge_lut+canny_lean+radius_staged radius_pre2 > $O/ab.log 2>&1; tail -8 $O/ab.log

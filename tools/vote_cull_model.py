@@ -42,7 +42,7 @@ def model(plane):
     octant = (sx < 0) * 4 + (sy < 0) * 2 + (np.abs(sx) > np.abs(sy)) * 1
     binx, biny = x // EB, y // EB
     out = dict(records=len(x), today_batches=0, today_lanes=0, today_items=0, oct_batches_test=0, oct_batches_all=0, oct_lanes=0,
-               oct_groups=0, oct_groups_skipped=0, oct_items=0, today_batches_all_both=0)
+               oct_groups=0, oct_groups_skipped=0, oct_items=0, today_batches_all_both=0, bin_trips=0, tile_items=[])
     for ty in range(0, h, VT):
         for tx in range(0, w, VT):
             lx0, ly0 = tx - 1, ty - 1
@@ -50,6 +50,7 @@ def model(plane):
             vx_hi, vy_hi = min(lx0 + VT + 2, w), min(ly0 + VT + 2, h)        # valid cells [lo, hi)
             bx0, bx1 = max(lx0 - MAXR, 0) // EB, min(lx0 + VT + 1 + MAXR, w - 1) // EB
             by0, by1 = max(ly0 - MAXR, 0) // EB, min(ly0 + VT + 1 + MAXR, h - 1) // EB
+            out["bin_trips"] += (bx1 - bx0 + 1) * (by1 - by0 + 1)          # the workgroup's bin loop visits every bin of the window, empty or not
             sel = (binx >= bx0) & (binx <= bx1) & (biny >= by0) & (biny <= by1)
             X, Y, SX, SY, O, BX, BY = x[sel], y[sel], sx[sel], sy[sel], octant[sel], binx[sel], biny[sel]
             # the kernel's per-lane test, both directions (fixed point, as in k_hough_circles.h)
@@ -59,6 +60,7 @@ def model(plane):
             mnx, mxx, mny, mxy = np.minimum(ax, bx_), np.maximum(ax, bx_), np.minimum(ay, by_), np.maximum(ay, by_)
             in_p = (X0 + mxx >= 0) & (X0 + mnx < xl) & (Y0 + mxy >= 0) & (Y0 + mny < yl)
             in_n = (X0 - mnx >= 0) & (X0 - mxx < xl) & (Y0 - mny >= 0) & (Y0 - mxy < yl)
+            out["tile_items"].append(int(in_p.sum() + in_n.sum()))         # (tools/valu_model.py: walks per workgroup)
             key = (BY - by0) * 8 + (BX - bx0)
             for k in np.unique(key):
                 m = key == k
@@ -99,6 +101,7 @@ if __name__ == "__main__":
         for v, plane in enumerate([b[0], b[1], b[4], b[5], b[6], b[7], b[8], b[9]]):
             r = model(plane)
             print("seed %d input %d: %s" % (s, v, r))
+            r.pop("tile_items")
             tot = r if tot is None else {k: tot[k] + r[k] for k in r}
     n = len(seeds)
     print("\nper diagram (8 inputs):")
