@@ -41,6 +41,18 @@ def test_version_and_switches(compat):
     assert set(compat) == {"grey_shift", "gauss_kernel_mode", "houghlines_numangle"}
 
 
+def test_product_probe_agrees_with_the_harness(compat):
+    """The package's own behavioural probe (pipeline.probe_cv2_switches: three closed-form probes, no oracle involved) on the live cv2
+    against the harness's selection (the oracle's kernels compared with cv2 on probe images): two independent readings of the same
+    module must name the same switch set -- until now the probe has only ever met the oracle-backed stand-in (tests/test_cv2_probe.py).
+    Also: the release table's entry for this version (from memory, pipeline.Params.opencv_switches) is checked against both."""
+    from img2sgf_amd import pipeline
+    got = pipeline.probe_cv2_switches(cv2)
+    want = dict(grey_shift=compat["grey_shift"], gauss_kernel_mode=compat["gauss_kernel_mode"], houghlines_numangle_mode=compat["houghlines_numangle"])
+    assert got == want, "cv2 %s: probe %s, harness %s" % (cv2.__version__, got, want)
+    assert pipeline.Params.opencv_switches(cv2.__version__) == want, "the release table is wrong for cv2 %s: %s" % (cv2.__version__, want)
+
+
 @pytest.mark.parametrize("name,img", list(_inputs()), ids=lambda v: v if isinstance(v, str) else "")
 def test_ten_calls_bytewise(name, img, compat):
     bad = H.compare(img, compat)
