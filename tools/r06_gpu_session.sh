@@ -18,5 +18,8 @@ grep -q " failed" $O/gputests.log && { timeout 1500 python -m pytest tests -m gp
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench_20_5.err; head -c 400 $O/bench_20_5.json; echo
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 timeout 900 bash tools/profile_round.sh r06 > $O/profile_round.log 2>&1; tail -3 $O/profile_round.log
+# 4b. which instruction classes SQ_INSTS_VALU counts (profiles/r06_valu_model.md: k_vote_centres' model is 10.8 % above the counter)
+( cd /tmp && export TMPDIR=/tmp && hipcc --offload-arch=gfx950 -O3 -w -o /tmp/sq_probe "$GRAFT_REPO_ROOT/tools/micro/sq_valu_count_probe.hip" && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/sq_probe_db -o r -- /tmp/sq_probe ) > $O/sq_valu_count_probe.log 2>&1
+python tools/rocpd_pmc.py /tmp/sq_probe_db/r_results.db $O/sq_valu_count_probe.csv > /dev/null 2>&1; head -20 $O/sq_valu_count_probe.csv
 # 5. the experiments that were proven bit-exact on the emulated kernels while the GPU was closed (tools/experiments/): A/B timings
 timeout 3000 bash tools/experiments/ab.sh stride133 tile128+cull_fast tile128 canny_lean edge_lut radius_staged tile128+vastr133 tile128+vastr133+cull_fast+edge_lut+canny_lean+radius_staged radius_pre2 > $O/ab.log 2>&1; tail -8 $O/ab.log
