@@ -14,6 +14,8 @@ for N in "$@"; do
   done
   # parity of the experimental build on the GPU: the parity module of the suite, through the same C ABI (I2S_LIBRARY: img2sgf_amd/_lib.py)
   I2S_EXPERIMENT=1 I2S_LIBRARY=$PWD/build/exp/$N/libi2s_hip.so timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "synthetic or reference_image or tiny or ragged or large or record_indices or phone or capacity" > $O/ab_${N}_parity.log 2>&1; echo "$N parity: $(tail -1 $O/ab_${N}_parity.log)"
+  # the Canny row kernels at every column-group boundary, on the hardware build (tests/stress/canny_widths.py takes any build of the library)
+  case "$N" in *canny_lean*) timeout 900 python tests/stress/canny_widths.py $PWD/build/exp/$N/libi2s_hip.so > $O/ab_${N}_canny_widths.log 2>&1; echo "$N canny widths: $(tail -1 $O/ab_${N}_canny_widths.log)";; esac
   python - "$O/ab_$N.txt" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
