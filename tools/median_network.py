@@ -19,9 +19,6 @@ strip borders do not count), vertical phase (column sorts, shared between output
 
 usage: python tools/median_network.py            -> the table of profiles/r06_b_median.md
 """
-import itertools
-import sys
-
 import numpy as np
 
 SORTERS = {      # optimal-size sorting networks (Knuth TAOCP 3, 5.3.4)
@@ -152,17 +149,9 @@ def merge(g, a, b, want=None):
             b.pop(0); lo -= 1; hi -= 1; changed = True
     key = ("merge", tuple(a), tuple(b)) if tuple(a) <= tuple(b) else ("merge", tuple(b), tuple(a))
     if key not in g.cache:
-        if len(a) % 2 == 1 and len(b) % 2 == 1 and False:
-            pass
         g.cache[key] = tuple(_oddeven_merge(g, a, b))
     full = g.cache[key]
     return list(full[lo:hi + 1])
-
-
-def keep_range(s, N):
-    """positions of a sorted list of s window elements that can still hold the median of N (rank m = (N-1)//2)."""
-    m = (N - 1) // 2
-    return max(0, s - 1 - m), min(s - 1, m)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -213,8 +213,10 @@ def sobel_model(code, rp, mode):
         return pre_common + peeled + 5 * trip + post_b
 
     def packed_wave(f_any):
+        # per trip of 6 rows: the worklist block runs once per band (1 row of 36), the two gradient blocks are skipped in the first trip only,
+        # 4 of a band's 36 rows emit nothing, and the suppression runs on the emitting rows that hold a magnitude above `low`
         trip = (fp["T"] - (1 - f_fix) * fp["fix"] - fp["worklist"] * (35.0 / 36) - sum(fp["grad"]) / 6.0
-                - sum(sorted(fp["emit"])[:0]) - (4.0 / 36) * 6 * np.mean(fp["emit"]) - (1 - f_any) * (32.0 / 36) * sum(fp["any"]))
+                - (4.0 / 36) * 6 * np.mean(fp["emit"]) - (1 - f_any) * (32.0 / 36) * sum(fp["any"]))
         return pre_common + pre_p + 6 * trip
 
     out = {}
