@@ -2,7 +2,7 @@
 figures of the code object's metadata, and the loop-level facts DESIGN.md's performance arguments rest on.
 
     python tools/isa_budget.py                 # compile with the product's flags, print the table
-    python tools/isa_budget.py -o profiles/r05_isa_budget.txt
+    python tools/isa_budget.py -o profiles/r06_isa_budget.txt
 
 tests/test_isa_budget.py asserts the budget below on every CPU run: the product is compiled in the build container with one HIP
 release and runs under another, and a compiler that starts packing f32 pairs, spills the median kernel or merges the blur kernel's
