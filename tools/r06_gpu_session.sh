@@ -22,7 +22,7 @@ timeout 900 bash tools/profile_round.sh r06 > $O/profile_round.log 2>&1; tail -3
 ( cd /tmp && export TMPDIR=/tmp && hipcc --offload-arch=gfx950 -O3 -w -o /tmp/sq_probe "$GRAFT_REPO_ROOT/tools/micro/sq_valu_count_probe.hip" && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/sq_probe_db -o r -- /tmp/sq_probe ) > $O/sq_valu_count_probe.log 2>&1
 python tools/rocpd_pmc.py /tmp/sq_probe_db/r_results.db $O/sq_valu_count_probe.csv > /dev/null 2>&1; head -20 $O/sq_valu_count_probe.csv
 # 5. the experiments that were proven bit-exact on the emulated kernels while the GPU was closed (tools/experiments/): A/B timings
-timeout 3000 bash tools/experiments/ab.sh stride133 tile128+cull_fast tile128 canny_lean edge_lut radius_staged tile128+vastr133 tile128+vastr133+cull_fast+edge_lut+canny_lean+radius_staged radius_pre2 tile128+cull_fast+vote_setup > $O/ab.log 2>&1; tail -8 $O/ab.log
+timeout 3000 bash tools/experiments/ab.sh stride133 tile128+cull_fast tile128 canny_lean edge_lut radius_staged tile128+vastr133 tile128+vastr133+cull_fast+edge_lut+canny_lean+radius_staged tile128+cull_fast+edge_lut+canny_lean+radius_staged radius_pre2 tile128+cull_fast+vote_setup > $O/ab.log 2>&1; tail -8 $O/ab.log
 # 6. the whole path with everything together: the bench line of the candidate build (its "lib" field names the file), beside the product's
 ALL=tile128+vastr133+cull_fast+edge_lut+canny_lean+radius_staged
 [ -f build/exp/$ALL/libi2s_hip.so ] && I2S_LIBRARY=$PWD/build/exp/$ALL/libi2s_hip.so timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $O/bench_candidate_20_5.json 2> $O/bench_candidate_20_5.err; head -c 300 $O/bench_candidate_20_5.json; echo
